@@ -1,0 +1,47 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def golden(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: d[k] for k in d.files}
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+SVC_KEYS = ["mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b"]
+SEP_KEYS = ["mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma", "beta_tilde_sigma",
+            "a", "b", "c"]
+STA_KEYS = ["mu_tilde_l", "sigma_tilde_l", "a", "b", "c"]
+
+
+def hyper_dict(vec, keys):
+    return {k: float(v) for k, v in zip(keys, vec)}
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1e-300, np.maximum(np.abs(a), np.abs(b)))))
+
+
+def vec_relerr(a, b):
+    """||a-b|| / ||b|| -- the gradient parity measure."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
