@@ -1,0 +1,174 @@
+/*
+ * nmgp.h -- C ABI of libnmgp_hip.so: the MI355X (gfx950) implementation of the multi-output
+ * Gaussian-process log-posterior path of Corleno/Nonstationary_Multivariate_Gaussian_Process.
+ *
+ * The reference has no FFI layer: its boundary is a set of Python module functions
+ * (Utility/{kernels,kronecker_operation,distributions,logpos}.py).  Every entry point below names the
+ * reference function (file:line under the reference tree) whose arithmetic it replaces; the Python
+ * package `nonstationary_multivariate_gaussian_process_amd.Utility` binds these symbols with ctypes
+ * behind the reference's own signatures (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; all scalars are double / int / long long.
+ *   - unless a name ends in `_dev`, array arguments are caller-owned HOST buffers, float64,
+ *     C-contiguous (row-major); the library copies in/out and owns all device memory.
+ *   - return value: 0 success; <0 API misuse (NMGP_E_*); >0 numerical failure:
+ *       k in [1, 1<<20)  : Cholesky failed, leading minor k not positive definite (rocSOLVER info)
+ *       NMGP_NUM_NAN     : a NaN/Inf reached the result
+ *       NMGP_NUM_EIG     : eigensolver did not converge
+ *     nmgp_last_error(ctx) returns a human readable message for the last non-zero return.
+ *   - a context is bound to one GPU and one HIP stream and is NOT thread-safe; use one per host thread.
+ *   - layouts follow the reference: Y is [N,M] row-major, the stacked observation vector is
+ *     output-major y[m*N+i] = Y[i,m] (logpos.py:338); the nonseparable parameter vector is
+ *     [tilde_l (N) | uL_vecs (N*T, location-major, tril row-major slots) | tilde_sigma2_err]
+ *     (logpos.py:32-43), the separable one [tilde_l (N) | tilde_sigma (N) | uL_vec (T) | tilde_sigma2_err]
+ *     (logpos.py:17-29), the stationary one [tilde_l, tilde_sigma, uL_vec (T), tilde_sigma2_err]
+ *     (logpos.py:46-57); T = M(M+1)/2.
+ */
+#ifndef NMGP_H
+#define NMGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMGP_VERSION 100
+
+/* API-misuse codes */
+#define NMGP_E_NULL        (-1)   /* required pointer is NULL */
+#define NMGP_E_SHAPE       (-2)   /* non-positive or inconsistent dimension */
+#define NMGP_E_STATE       (-3)   /* call order violated (e.g. eval before nmgp_set_data) */
+#define NMGP_E_UNSUPPORTED (-4)   /* M larger than NMGP_MAX_OUTPUTS, etc. */
+#define NMGP_E_HIP         (-5)   /* HIP / rocBLAS / rocSOLVER runtime error (see nmgp_last_error) */
+#define NMGP_E_NOMEM       (-6)
+/* numerical-failure codes (positive) */
+#define NMGP_NUM_NAN       (1 << 20)
+#define NMGP_NUM_EIG       ((1 << 20) + 1)
+
+#define NMGP_MAX_OUTPUTS 8
+
+typedef struct nmgp_ctx nmgp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device = HIP device ordinal. */
+int nmgp_ctx_create(int device, nmgp_ctx** out);
+int nmgp_ctx_destroy(nmgp_ctx* ctx);
+const char* nmgp_last_error(const nmgp_ctx* ctx);
+int nmgp_version(void);
+/* Blocks until all work queued on the context's stream is complete. */
+int nmgp_sync(nmgp_ctx* ctx);
+/* Number of visible HIP devices (does not create a context). */
+int nmgp_device_count(void);
+
+/* ---- data residency ------------------------------------------------------------------------ */
+/* Upload one subject's inputs (x: [N], Y: [N,M] row-major) and size all workspaces.  Replaces the
+ * per-call tensor plumbing of logpos.py:337-338.  May be called again with another subject. */
+int nmgp_set_data(nmgp_ctx* ctx, const double* x, const double* Y, int N, int M);
+
+/* ---- nonseparable ("SVC") objective:  logpos.nlogpos_obj_SVC / logpos_SVC, logpos.py:299-380 -- */
+/* hyper[8] = {mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_L, alpha_L, beta_L, a, b}.
+ * out5 = {NegLog, loglik, log_prior_tilde_l, log_prior_uL_vecs, log_prior_sigma2_err} (the verbose tuple).
+ * prior = the reference's `Prior` flag.  grad (length N(1+T)+1) receives d NegLog / d pars, or pass NULL.
+ * Synchronous. */
+int nmgp_logpos_svc(nmgp_ctx* ctx, const double* pars, const double hyper[8], int prior,
+                    double out5[5], double* grad);
+
+/* Resident form used by MCMC/MAP loops and the benchmark: the parameter vector lives in HBM
+ * (nmgp_svc_pars_dev returns its device address, length N(1+T)+1; nmgp_svc_set_pars copies a host
+ * vector into it).  nmgp_svc_eval_resident only enqueues work on the context's stream; results stay on
+ * the device until nmgp_svc_fetch (which synchronises, checks the factorisation status and copies
+ * out5 / grad). */
+int nmgp_svc_set_pars(nmgp_ctx* ctx, const double* pars);
+double* nmgp_svc_pars_dev(nmgp_ctx* ctx);
+double* nmgp_svc_grad_dev(nmgp_ctx* ctx);
+int nmgp_svc_eval_resident(nmgp_ctx* ctx, const double hyper[8], int prior, int want_grad);
+int nmgp_svc_fetch(nmgp_ctx* ctx, double out5[5], double* grad);
+
+/* Dense covariance of the nonseparable model as the reference assembles it (logpos.py:339-353:
+ * K_x, generate_K_index_SVC, the n-major->m-major permutation, kron(ones, K_x) * K_i, + sigma2 I).
+ * out: [MN, MN] full symmetric, output-major.  For tests and for callers that want Sigma itself. */
+int nmgp_svc_covariance(nmgp_ctx* ctx, const double* pars, double* out);
+
+/* ---- separable objective:  logpos.nlogpos_obj / logpos, logpos.py:216-296 ------------------- */
+/* hyper[9] = {mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_tilde_sigma, alpha_tilde_sigma,
+ *             beta_tilde_sigma, a, b, c};
+ * out6 = {NegLog, loglik, lp_tilde_l, lp_tilde_sigma, lp_uL_vec, lp_sigma2_err}; grad length 2N+T+1. */
+int nmgp_logpos_sep(nmgp_ctx* ctx, const double* pars, const double hyper[9], int prior,
+                    double out6[6], double* grad);
+
+/* ---- stationary objective:  logpos.nlogpos_obj_S / logpos_S, logpos.py:383-462 -------------- */
+/* hyper[5] = {mu_tilde_l, sigma_tilde_l, a, b, c}; out5 = {NegLog, loglik, lp_tilde_l, lp_uL_vec,
+ * lp_sigma2_err}; grad length T+3. */
+int nmgp_logpos_sta(nmgp_ctx* ctx, const double* pars, const double hyper[5], int prior,
+                    double out5[5], double* grad);
+
+/* ---- primitives (host buffers in / out) ----------------------------------------------------- */
+/* kernels.pairwise_distances, kernels.py:5-21.  x1: [n1,d], x2: [n2,d] or NULL (=x1). out: [n1,n2]. */
+int nmgp_pairwise_distances(nmgp_ctx* ctx, const double* x1, int n1, const double* x2, int n2, int d,
+                            double* out);
+/* kernels.RBF_cov, kernels.py:24-43.  x2 == NULL selects the symmetric form with jitter*I. */
+int nmgp_rbf_cov(nmgp_ctx* ctx, const double* x1, int n1, const double* x2, int n2, int d,
+                 double alpha, double beta, double* out);
+/* kernels.Nonstationary_RBF_cov, kernels.py:46-73.  s1/l1 (s2/l2) may be NULL (= ones). */
+int nmgp_nonstat_rbf_cov(nmgp_ctx* ctx, const double* x1, const double* s1, const double* l1, int n1,
+                         const double* x2, const double* s2, const double* l2, int n2, int d,
+                         double* out);
+/* kronecker_operation.kronecker_product, kronecker_operation.py:5-22.  a: [ar,ac], b: [br,bc]. */
+int nmgp_kron_product(nmgp_ctx* ctx, const double* a, int ar, int ac, const double* b, int br, int bc,
+                      double* out);
+/* kronecker_operation.kron_mv, kronecker_operation.py:72-85.  B: [m1,m2], K: [n1,n2], y: [m2*n2]
+ * (output-major), out: [m1*n1]. */
+int nmgp_kron_mv(nmgp_ctx* ctx, const double* B, int m1, int m2, const double* K, int n1, int n2,
+                 const double* y, double* out);
+/* distributions.multivariate_normal_logpdf, distributions.py:10-23: -0.5 logdet - 0.5 (y-mu)' invSigma (y-mu)
+ * for a caller-supplied inverse [n,n] and log-determinant (mu may be NULL = zeros). */
+int nmgp_mvn_logpdf(nmgp_ctx* ctx, const double* y, const double* mu, double logdetSigma,
+                    const double* invSigma, int n, double* out);
+/* distributions.multivariate_normal_logpdf0, distributions.py:26-52: log density (without 2 pi) of
+ * N(mu, B kron K + sigma2 I) in the joint eigenbasis.  B: [M,M], K: [N,N], y/mu: [MN] (mu may be NULL). */
+int nmgp_mvn_logpdf_kron(nmgp_ctx* ctx, const double* y, const double* mu, const double* B, int M,
+                         const double* K, int N, double sigma2, double* out);
+/* distributions.multivariate_normal_logpdf2, distributions.py:99-113 (dense Cholesky evaluation). */
+int nmgp_mvn_logpdf_dense(nmgp_ctx* ctx, const double* y, const double* mu, const double* B, int M,
+                          const double* K, int N, double sigma2, double* out);
+/* kronecker_operation.kron_inv / kron_logdet, kronecker_operation.py:36-69. out_inv: [MN,MN]. */
+int nmgp_kron_inv_logdet(nmgp_ctx* ctx, double sigma2, const double* B, int M, const double* K, int N,
+                         double* out_inv, double* out_logdet);
+
+/* ---- deterministic prediction (prediction.py:912-988, 337-408, 1566-1638) -------------------- */
+/* Nonseparable: predictive mean / variance of y at S new inputs xs given MAP parameters.
+ * mean, var: [S,M]; Lstar: [S,T] (predicted L_vec at xs, exp already applied on the diagonal slots). */
+int nmgp_predict_svc(nmgp_ctx* ctx, const double* pars, const double hyper[8], const double* xs, int S,
+                     double* mean, double* var, double* Lstar);
+int nmgp_predict_sep(nmgp_ctx* ctx, const double* pars, const double hyper[9], const double* xs, int S,
+                     double* mean, double* var);
+int nmgp_predict_sta(nmgp_ctx* ctx, const double* pars, const double* xs, int S, double* mean,
+                     double* var);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Per-stage HIP-event timing on the context's stream (bench.py roofline figures).  Stages: */
+enum {
+    NMGP_STAGE_COV = 0,     /* fused covariance build (kernel #1)            */
+    NMGP_STAGE_CHOL = 1,    /* Cholesky factorisation of Sigma               */
+    NMGP_STAGE_SOLVE = 2,   /* triangular solve(s) with y                    */
+    NMGP_STAGE_REDUCE = 3,  /* log-det / quadratic-form reductions + combine */
+    NMGP_STAGE_PRIOR = 4,   /* GP priors (cached factors, trsm)              */
+    NMGP_STAGE_INVERSE = 5, /* Sigma^-1 for the gradient                     */
+    NMGP_STAGE_ADJOINT = 6, /* fused adjoint contraction (kernel #5)         */
+    NMGP_STAGE_EIG = 7,     /* eigendecomposition (separable / stationary)   */
+    NMGP_STAGE_KRONMV = 8,  /* Kron-vec contraction (kernel #3)              */
+    NMGP_STAGE_COUNT = 9
+};
+int nmgp_profile_enable(nmgp_ctx* ctx, int on);
+/* Accumulated milliseconds and launch counts per stage since the last reset; synchronises. */
+int nmgp_profile_read(nmgp_ctx* ctx, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT]);
+int nmgp_profile_reset(nmgp_ctx* ctx);
+/* Micro-benchmarks used to state measured peaks next to the spec ones: HBM stream (GB/s) and a
+ * rocBLAS dgemm of size n (TFLOP/s). */
+int nmgp_measure_hbm_gbs(nmgp_ctx* ctx, long long bytes, int reps, double* gbs);
+int nmgp_measure_dgemm_tflops(nmgp_ctx* ctx, int n, int reps, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMGP_H */

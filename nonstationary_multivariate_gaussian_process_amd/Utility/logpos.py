@@ -1,0 +1,228 @@
+"""Log-posterior objectives behind the reference's signatures (reference: Utility/logpos.py).
+
+``nlogpos_obj_SVC`` / ``nlogpos_obj`` / ``nlogpos_obj_S`` take CPU float64 tensors exactly like the reference
+and return CPU 0-d float64 tensors attached to autograd; the value AND the gradient are produced by one fused
+evaluation on the MI355X (libnmgp_hip.so: covariance build, Cholesky / eigendecomposition, reductions, analytic
+adjoint), so ``NegLog.backward()`` (Nonseparable_model.py:171) and ``torch.autograd.grad`` both work.
+There is no CPU fallback: a missing library or GPU raises.
+"""
+import numpy as np
+import torch
+
+from . import distributions  # noqa: F401
+from . import kernels
+from . import kronecker_operation  # noqa: F401
+from . import settings
+from . import utils
+from .. import _lib
+from ._bridge import ctx, to_np
+
+hyper_pars = {"mu_tilde_l": 0., "alpha_tilde_l": 1., "beta_tilde_l": 1., "mu_tilde_sigma": 0.,
+              "alpha_tilde_sigma": 1., "beta_tilde_sigma": 1., "a": 1, "b": 1, "c": 10}
+
+
+# ---- parameter vector slicing (reference logpos.py:17-71) -------------------------------------------
+def vec2pars(pars, N, M):
+    """[tilde_l (N) | tilde_sigma (N) | L_vec (T) | tilde_sigma2_err]; reference logpos.py:17-29."""
+    return pars[:N], pars[N:2 * N], pars[2 * N:2 * N + int(M * (M + 1) / 2)], pars[-1]
+
+
+def vec2pars_SVC(pars, N, M):
+    """[tilde_l (N) | L_vecs (N*T) | tilde_sigma2_err]; reference logpos.py:32-43."""
+    return pars[:N], pars[N: N + N * int(M * (M + 1) / 2)], pars[-1]
+
+
+def vec2pars_S(pars, M):
+    """[tilde_l, tilde_sigma, L_vec (T), tilde_sigma2_err]; reference logpos.py:46-57."""
+    return pars[0], pars[1], pars[2: 2 + int(M * (M + 1) / 2)], pars[-1]
+
+
+def vec2pars_hadamard_SVC(pars, N, M):
+    """reference logpos.py:60-71 (same slicing as vec2pars_SVC)."""
+    return vec2pars_SVC(pars, N, M)
+
+
+# ---- index helpers (reference logpos.py:74-118) ---------------------------------------------------
+def generate_vectorized_indexes(indx1, indx2):
+    """reference logpos.py:74-85."""
+    N1, N2 = indx1.size(0), indx2.size(0)
+    return (indx1.view(-1, 1).repeat(1, N2).view(-1).type(torch.LongTensor),
+            indx2.repeat(N1).type(torch.LongTensor))
+
+
+def generate_K_index(B_f, indx):
+    """reference logpos.py:88-99."""
+    N = indx.size(0)
+    i1, i2 = generate_vectorized_indexes(indx, indx)
+    return B_f[i1, i2].view([N, N])
+
+
+def generate_K_index_SVC(L_f_list):
+    """cat(L_f) cat(L_f)^T, location-major [NM, NM]; reference logpos.py:111-118.  (The fused GPU objective never
+    materialises this matrix; the function is kept for callers that want it.)"""
+    L = torch.cat(L_f_list, dim=0)
+    return L.mm(L.t())
+
+
+# ---- fused objectives on the GPU ----------------------------------------------------------------
+def _f(v):
+    return float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+
+
+class _FusedObjective(torch.autograd.Function):
+    """value + gradient of one of the three objectives from a single C-ABI call.
+
+    forward(kind, prior, hyper(list), Y, x, *param_pieces) -> tuple of 0-d tensors (first is the log posterior
+    ``res`` -- NOT negated -- the rest are the verbose components, marked non-differentiable)."""
+
+    @staticmethod
+    def forward(fctx, kind, prior, hyper, Y, x, *pieces):
+        c = ctx()
+        c.set_data(x, Y)
+        flat = np.concatenate([to_np(p).reshape(-1) for p in pieces])
+        want_grad = any(isinstance(p, torch.Tensor) and p.requires_grad for p in pieces)
+        try:
+            if kind == "svc":
+                out, grad = c.logpos_svc(flat, hyper, prior, want_grad)
+            elif kind == "sep":
+                out, grad = c.logpos_sep(flat, hyper, prior, want_grad)
+            else:
+                out, grad = c.logpos_sta(flat, hyper, prior, want_grad)
+        except _lib.NmgpNumericalError as e:
+            if kind == "svc":
+                # torch.inverse raises on a singular covariance (reference logpos.py:352)
+                raise RuntimeError("nlogpos_obj_SVC: %s" % e)
+            # the eigen path yields NaN in the reference (callers test `loglik != loglik`, logpos.py:267)
+            nout = 6 if kind == "sep" else 5
+            out, grad = np.full(nout, np.nan), (np.full(flat.shape[0], np.nan) if want_grad else None)
+        fctx.shapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in pieces]
+        fctx.grad_np = grad          # d NegLog / d pars
+        res = [torch.tensor(-out[0]).type(settings.torchType)]
+        res += [torch.tensor(v).type(settings.torchType) for v in out[1:]]
+        fctx.mark_non_differentiable(*res[1:])
+        return tuple(res)
+
+    @staticmethod
+    def backward(fctx, gres, *unused):
+        g = fctx.grad_np
+        outs = [None, None, None, None, None]
+        if g is None:
+            return tuple(outs + [None] * len(fctx.shapes))
+        scale = -float(gres)          # grad_np is for NegLog = -res
+        k = 0
+        for shp in fctx.shapes:
+            if shp is None:
+                outs.append(None)
+                k += 1
+                continue
+            cnt = int(np.prod(shp)) if len(shp) else 1
+            outs.append(torch.from_numpy(g[k:k + cnt] * scale).type(settings.torchType).reshape(shp))
+            k += cnt
+        return tuple(outs)
+
+
+def _as_tensor(v):
+    return v if isinstance(v, torch.Tensor) else torch.tensor(float(v)).type(settings.torchType)
+
+
+# ---- nonseparable ("SVC") model: reference logpos.py:299-380 ------------------------------------------
+def nlogpos_obj_SVC(pars, Y, x, mu_tilde_l=0., alpha_tilde_l=5., beta_tilde_l=1., mu_L=0., alpha_L=5., beta_L=1., a=1,
+                    b=1, verbose=False, Prior=True):
+    """Negative log posterior of the nonseparable model on the flat parameter vector
+    [tilde_l | uL_vecs | tilde_sigma2_err]; verbose=True returns (NegLog, loglik, lp_tilde_l, lp_uL_vecs, lp_sigma2_err).
+    reference logpos.py:299-323."""
+    N, M = Y.size()
+    tilde_l, uL_vecs, tilde_sigma2_err = vec2pars_SVC(pars, N, M)
+    if verbose:
+        res, loglik, lp_l, lp_uL, lp_s2 = logpos_SVC(tilde_l, uL_vecs, tilde_sigma2_err, Y, x, mu_tilde_l,
+                                                     alpha_tilde_l, beta_tilde_l, mu_L, alpha_L, beta_L, a, b, verbose,
+                                                     Prior)
+        return -res, loglik, lp_l, lp_uL, lp_s2
+    return -logpos_SVC(tilde_l, uL_vecs, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_L,
+                       alpha_L, beta_L, a, b, verbose, Prior)
+
+
+def logpos_SVC(tilde_l, uL_vecs, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_L, alpha_L, beta_L,
+               a, b, verbose=False, Prior=True):
+    """Log joint posterior of the nonseparable model; reference logpos.py:326-380.  One fused GPU evaluation:
+    kernel #1 (Gibbs kernel x per-location L_i L_j^T, Kronecker placement, + sigma2 I), Cholesky, reductions,
+    cached-factor GP priors, and -- when a parameter requires grad -- the analytic adjoint (kernel #5)."""
+    hyper = [_f(mu_tilde_l), _f(alpha_tilde_l), _f(beta_tilde_l), _f(mu_L), _f(alpha_L), _f(beta_L), _f(a), _f(b)]
+    res = _FusedObjective.apply("svc", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(uL_vecs),
+                                _as_tensor(tilde_sigma2_err))
+    return res if verbose else res[0]
+
+
+# ---- separable model: reference logpos.py:216-296 -------------------------------------------------
+def nlogpos_obj(pars, Y, x, mu_tilde_l=0., alpha_tilde_l=1., beta_tilde_l=1., mu_tilde_sigma=0., alpha_tilde_sigma=1.,
+                beta_tilde_sigma=1., a=1, b=1, c=10, verbose=False, Prior=True):
+    """Negative log posterior of the separable nonstationary model; reference logpos.py:216-234."""
+    N, M = Y.size()
+    tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err = vec2pars(pars, N, M)
+    if verbose:
+        res, loglik, lp_l, lp_s, lp_uL, lp_s2 = logpos(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l,
+                                                       alpha_tilde_l, beta_tilde_l, mu_tilde_sigma, alpha_tilde_sigma,
+                                                       beta_tilde_sigma, a, b, c, verbose, Prior)
+        return -res, loglik, lp_l, lp_s, lp_uL, lp_s2
+    return -logpos(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde_l, beta_tilde_l,
+                   mu_tilde_sigma, alpha_tilde_sigma, beta_tilde_sigma, a, b, c, verbose, Prior)
+
+
+def logpos(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_tilde_sigma,
+           alpha_tilde_sigma, beta_tilde_sigma, a, b, c, verbose=False, Prior=True):
+    """Log joint posterior of the separable model; reference logpos.py:237-296 (Kronecker eigen-trick likelihood
+    of distributions.py:26-52, two GP priors, Normal(0,c) on uL_vec, inverse-gamma, Jacobian).  A numerical failure of
+    the first attempt yields NaN like the reference's; its random-jitter retry loop (:267-268) is nondeterministic
+    and is not reproduced."""
+    hyper = [_f(mu_tilde_l), _f(alpha_tilde_l), _f(beta_tilde_l), _f(mu_tilde_sigma), _f(alpha_tilde_sigma),
+             _f(beta_tilde_sigma), _f(a), _f(b), _f(c)]
+    res = _FusedObjective.apply("sep", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
+                                _as_tensor(uL_vec), _as_tensor(tilde_sigma2_err))
+    return res if verbose else res[0]
+
+
+# ---- stationary model: reference logpos.py:383-462 -------------------------------------------------
+def nlogpos_obj_S(pars, Y, x, mu_tilde_l, sigma_tilde_l, a=1, b=1, c=10, verbose=False, Prior=True):
+    """Negative log posterior of the stationary (LMC) model; reference logpos.py:383-402."""
+    N, M = Y.size()
+    tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err = vec2pars_S(pars, M)
+    if verbose:
+        res, loglik, lp_l, lp_uL, lp_s2 = logpos_S(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l,
+                                                   sigma_tilde_l, a, b, c, verbose, Prior)
+        return -res, loglik, lp_l, lp_uL, lp_s2
+    return -logpos_S(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, sigma_tilde_l, a, b, c, verbose,
+                     Prior)
+
+
+def logpos_S(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, sigma_tilde_l, a, b, c, verbose=False,
+             Prior=True):
+    """Log joint posterior of the stationary model; reference logpos.py:405-462."""
+    if verbose and not Prior:
+        # the reference leaves log_prior_tilde_l unbound in this combination (logpos.py:459)
+        raise UnboundLocalError("local variable 'log_prior_tilde_l' referenced before assignment")
+    hyper = [_f(mu_tilde_l), _f(sigma_tilde_l), _f(a), _f(b), _f(c)]
+    res = _FusedObjective.apply("sta", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
+                                _as_tensor(uL_vec), _as_tensor(tilde_sigma2_err))
+    return res if verbose else res[0]
+
+
+# ---- deviance (reference logpos.py:176-213) ---------------------------------------------------------
+def deviance_obj(pars, Y, x):
+    """reference logpos.py:176-187."""
+    N, M = Y.size()
+    tilde_l, tilde_sigma, L_vec, tilde_sigma2_err = vec2pars(pars, N, M)
+    return deviance(tilde_l, tilde_sigma, L_vec, tilde_sigma2_err, Y, x)
+
+
+def deviance(tilde_l, tilde_sigma, L_vec, tilde_sigma2_err, Y, x):
+    """-2 loglik of the separable likelihood with L_vec taken as-is (no exp reparametrisation);
+    reference logpos.py:190-213 (kron_inv + kron_logdet + multivariate_normal_logpdf there)."""
+    N, M = Y.size()
+    y = Y.t().contiguous().view(-1)
+    L = utils.vec2lowtriangle(L_vec.detach() if isinstance(L_vec, torch.Tensor) else L_vec, M)
+    B_f = torch.mm(L, L.t())
+    K_x = kernels.Nonstationary_RBF_cov(x.view([-1, 1]), sigma1=torch.exp(tilde_sigma.detach()),
+                                        ell1=torch.exp(tilde_l.detach()))
+    loglik = distributions.multivariate_normal_logpdf0(y, torch.zeros_like(y), B_f, K_x,
+                                                       torch.exp(_as_tensor(tilde_sigma2_err).detach()))
+    return -2 * loglik

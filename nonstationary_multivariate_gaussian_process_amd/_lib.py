@@ -1,0 +1,368 @@
+"""ctypes binding of libnmgp_hip.so (the C ABI declared in include/nmgp.h).
+
+The product path has NO CPU fallback: if the shared object is missing, cannot be loaded, or no MI355X is
+visible, every compute entry raises.  Only ``load(require_gpu=False)`` is allowed without a GPU and only
+resolves symbols (used by the CPU test-suite to check the ABI surface).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libnmgp_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_ll_p = ctypes.POINTER(ctypes.c_longlong)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+I, D, P, V = ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_void_p
+
+NUM_NAN = 1 << 20
+NUM_EIG = (1 << 20) + 1
+STAGES = ["cov", "chol", "solve", "reduce", "prior", "inverse", "adjoint", "eig", "kronmv"]
+
+# name -> (restype, argtypes); must list every function declared in include/nmgp.h
+SIGNATURES = {
+    "nmgp_ctx_create": (I, [I, c_void_pp]),
+    "nmgp_ctx_destroy": (I, [V]),
+    "nmgp_last_error": (ctypes.c_char_p, [V]),
+    "nmgp_version": (I, []),
+    "nmgp_sync": (I, [V]),
+    "nmgp_device_count": (I, []),
+    "nmgp_set_data": (I, [V, P, P, I, I]),
+    "nmgp_logpos_svc": (I, [V, P, P, I, P, P]),
+    "nmgp_svc_set_pars": (I, [V, P]),
+    "nmgp_svc_pars_dev": (V, [V]),
+    "nmgp_svc_grad_dev": (V, [V]),
+    "nmgp_svc_eval_resident": (I, [V, P, I, I]),
+    "nmgp_svc_fetch": (I, [V, P, P]),
+    "nmgp_svc_covariance": (I, [V, P, P]),
+    "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
+    "nmgp_logpos_sta": (I, [V, P, P, I, P, P]),
+    "nmgp_pairwise_distances": (I, [V, P, I, P, I, I, P]),
+    "nmgp_rbf_cov": (I, [V, P, I, P, I, I, D, D, P]),
+    "nmgp_nonstat_rbf_cov": (I, [V, P, P, P, I, P, P, P, I, I, P]),
+    "nmgp_kron_product": (I, [V, P, I, I, P, I, I, P]),
+    "nmgp_kron_mv": (I, [V, P, I, I, P, I, I, P, P]),
+    "nmgp_mvn_logpdf": (I, [V, P, P, D, P, I, P]),
+    "nmgp_mvn_logpdf_kron": (I, [V, P, P, P, I, P, I, D, P]),
+    "nmgp_mvn_logpdf_dense": (I, [V, P, P, P, I, P, I, D, P]),
+    "nmgp_kron_inv_logdet": (I, [V, D, P, I, P, I, P, P]),
+    "nmgp_predict_svc": (I, [V, P, P, P, I, P, P, P]),
+    "nmgp_predict_sep": (I, [V, P, P, P, I, P, P]),
+    "nmgp_predict_sta": (I, [V, P, P, I, P, P]),
+    "nmgp_profile_enable": (I, [V, I]),
+    "nmgp_profile_read": (I, [V, P, c_ll_p]),
+    "nmgp_profile_reset": (I, [V]),
+    "nmgp_measure_hbm_gbs": (I, [V, ctypes.c_longlong, I, P]),
+    "nmgp_measure_dgemm_tflops": (I, [V, I, I, P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NmgpError(RuntimeError):
+    """API misuse or HIP runtime failure reported by libnmgp_hip.so (negative return code)."""
+
+
+class NmgpNumericalError(RuntimeError):
+    """Numerical failure (positive return code): covariance not positive definite, NaN, eigensolver."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def load(require_gpu=True):
+    """Load the shared object and bind every symbol of the ABI.  Raises if it is absent: there is no fallback."""
+    global _lib
+    # torch bundles its own ROCm runtime (libamdhip64 / rocBLAS / rocSOLVER with the same sonames as /opt/rocm).
+    # Two HIP runtimes in one process crash, so torch must be loaded FIRST: libnmgp_hip.so then binds to the copies
+    # already in the process.  (A pure C/C++ host links /opt/rocm directly; see INTEGRATION.md.)
+    import torch  # noqa: F401
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NmgpError(
+                    "libnmgp_hip.so is missing (%s). Build it with `python -m "
+                    "nonstationary_multivariate_gaussian_process_amd.build` (needs hipcc); this package has no CPU "
+                    "fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)        # AttributeError if the .so does not export it
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    if require_gpu and _lib.nmgp_device_count() <= 0:
+        raise NmgpError("no HIP device is visible: the MI355X path cannot run (and there is no CPU fallback)")
+    return _lib
+
+
+def as_f64(a):
+    """Contiguous float64 ndarray view/copy of array-like or CPU torch tensor."""
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+class Context:
+    """One nmgp_ctx: one GPU, one stream, one resident subject.  Not thread-safe."""
+
+    def __init__(self, device=None):
+        self.lib = load(require_gpu=True)
+        if device is None:
+            device = default_device()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.nmgp_ctx_create(self.device, ctypes.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self.lib.nmgp_last_error(h).decode() if h else "nmgp_ctx_create failed"
+            raise NmgpError("nmgp_ctx_create(device=%d) -> %d: %s" % (self.device, rc, msg))
+        self.N = self.M = self.T = 0
+        self._data_key = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmgp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error mapping --------------------------------------------------------------------------
+    def check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.nmgp_last_error(self.h).decode()
+        if rc > 0:
+            raise NmgpNumericalError(rc, msg)
+        raise NmgpError("libnmgp_hip error %d: %s" % (rc, msg))
+
+    # -- data -----------------------------------------------------------------------------------
+    def set_data(self, x, Y):
+        x = as_f64(x).reshape(-1)
+        Y = as_f64(Y)
+        if Y.ndim != 2 or Y.shape[0] != x.shape[0]:
+            raise NmgpError("Y must be [N, M] with N == len(x); got Y%s x%s" % (Y.shape, x.shape))
+        key = (x.shape, Y.shape, hash(x.tobytes()), hash(Y.tobytes()))
+        if key == self._data_key:
+            return
+        self.check(self.lib.nmgp_set_data(self.h, ptr(x), ptr(Y), Y.shape[0], Y.shape[1]))
+        self.N, self.M = Y.shape
+        self.T = self.M * (self.M + 1) // 2
+        self._data_key = key
+
+    def sync(self):
+        self.check(self.lib.nmgp_sync(self.h))
+
+    # -- nonseparable ---------------------------------------------------------------------------
+    def logpos_svc(self, pars, hyper, prior=True, want_grad=False):
+        pars = as_f64(pars).reshape(-1)
+        P_ = self.N * (1 + self.T) + 1
+        if pars.shape[0] != P_:
+            raise NmgpError("parameter vector has length %d, expected N(1+T)+1 = %d" % (pars.shape[0], P_))
+        hyper = as_f64(hyper)
+        out = np.empty(5)
+        grad = np.empty(P_) if want_grad else None
+        self.check(self.lib.nmgp_logpos_svc(self.h, ptr(pars), ptr(hyper), int(bool(prior)), ptr(out), ptr(grad)))
+        return out, grad
+
+    def svc_set_pars(self, pars):
+        pars = as_f64(pars).reshape(-1)
+        if pars.shape[0] != self.N * (1 + self.T) + 1:
+            raise NmgpError("bad parameter vector length %d" % pars.shape[0])
+        self.check(self.lib.nmgp_svc_set_pars(self.h, ptr(pars)))
+        self.sync()      # the host buffer may be a temporary
+
+    def svc_eval_resident(self, hyper, prior=True, want_grad=False):
+        hyper = as_f64(hyper)
+        self.check(self.lib.nmgp_svc_eval_resident(self.h, ptr(hyper), int(bool(prior)), int(bool(want_grad))))
+
+    def svc_fetch(self, want_grad=False):
+        out = np.empty(5)
+        grad = np.empty(self.N * (1 + self.T) + 1) if want_grad else None
+        self.check(self.lib.nmgp_svc_fetch(self.h, ptr(out), ptr(grad)))
+        return out, grad
+
+    def svc_covariance(self, pars):
+        pars = as_f64(pars).reshape(-1)
+        n = self.N * self.M
+        out = np.empty((n, n))
+        self.check(self.lib.nmgp_svc_covariance(self.h, ptr(pars), ptr(out)))
+        return out
+
+    # -- separable / stationary -------------------------------------------------------------------
+    def logpos_sep(self, pars, hyper, prior=True, want_grad=False):
+        pars = as_f64(pars).reshape(-1)
+        P_ = 2 * self.N + self.T + 1
+        if pars.shape[0] != P_:
+            raise NmgpError("parameter vector has length %d, expected 2N+T+1 = %d" % (pars.shape[0], P_))
+        hyper = as_f64(hyper)
+        out = np.empty(6)
+        grad = np.empty(P_) if want_grad else None
+        self.check(self.lib.nmgp_logpos_sep(self.h, ptr(pars), ptr(hyper), int(bool(prior)), ptr(out), ptr(grad)))
+        return out, grad
+
+    def logpos_sta(self, pars, hyper, prior=True, want_grad=False):
+        pars = as_f64(pars).reshape(-1)
+        P_ = self.T + 3
+        if pars.shape[0] != P_:
+            raise NmgpError("parameter vector has length %d, expected T+3 = %d" % (pars.shape[0], P_))
+        hyper = as_f64(hyper)
+        out = np.empty(5)
+        grad = np.empty(P_) if want_grad else None
+        self.check(self.lib.nmgp_logpos_sta(self.h, ptr(pars), ptr(hyper), int(bool(prior)), ptr(out), ptr(grad)))
+        return out, grad
+
+    # -- primitives -----------------------------------------------------------------------------
+    def pairwise_distances(self, x1, x2=None):
+        x1 = as_f64(x1)
+        x2a = None if x2 is None else as_f64(x2)
+        n1, d = x1.shape
+        n2 = n1 if x2a is None else x2a.shape[0]
+        out = np.empty((n1, n2))
+        self.check(self.lib.nmgp_pairwise_distances(self.h, ptr(x1), n1, ptr(x2a), n2, d, ptr(out)))
+        return out
+
+    def rbf_cov(self, x1, x2=None, alpha=1.0, beta=1.0):
+        x1 = as_f64(x1)
+        x2a = None if x2 is None else as_f64(x2)
+        n1, d = x1.shape
+        n2 = n1 if x2a is None else x2a.shape[0]
+        out = np.empty((n1, n2))
+        self.check(self.lib.nmgp_rbf_cov(self.h, ptr(x1), n1, ptr(x2a), n2, d, float(alpha), float(beta), ptr(out)))
+        return out
+
+    def nonstat_rbf_cov(self, x1, s1=None, l1=None, x2=None, s2=None, l2=None):
+        x1 = as_f64(x1)
+        n1, d = x1.shape
+        s1a = None if s1 is None else as_f64(s1).reshape(-1)
+        l1a = None if l1 is None else as_f64(l1).reshape(-1)
+        x2a = None if x2 is None else as_f64(x2)
+        s2a = None if (x2 is None or s2 is None) else as_f64(s2).reshape(-1)
+        l2a = None if (x2 is None or l2 is None) else as_f64(l2).reshape(-1)
+        n2 = n1 if x2a is None else x2a.shape[0]
+        out = np.empty((n1, n2))
+        self.check(self.lib.nmgp_nonstat_rbf_cov(self.h, ptr(x1), ptr(s1a), ptr(l1a), n1, ptr(x2a), ptr(s2a), ptr(l2a),
+                                                 n2, d, ptr(out)))
+        return out
+
+    def kron_product(self, a, b):
+        a, b = as_f64(a), as_f64(b)
+        out = np.empty((a.shape[0] * b.shape[0], a.shape[1] * b.shape[1]))
+        self.check(self.lib.nmgp_kron_product(self.h, ptr(a), a.shape[0], a.shape[1], ptr(b), b.shape[0], b.shape[1],
+                                              ptr(out)))
+        return out
+
+    def kron_mv(self, B, K, y):
+        B, K, y = as_f64(B), as_f64(K), as_f64(y).reshape(-1)
+        if y.shape[0] != B.shape[1] * K.shape[1]:
+            raise NmgpError("kron_mv: y has length %d, expected %d" % (y.shape[0], B.shape[1] * K.shape[1]))
+        out = np.empty(B.shape[0] * K.shape[0])
+        self.check(self.lib.nmgp_kron_mv(self.h, ptr(B), B.shape[0], B.shape[1], ptr(K), K.shape[0], K.shape[1], ptr(y),
+                                         ptr(out)))
+        return out
+
+    def mvn_logpdf(self, y, mu, logdet, inv):
+        y, inv = as_f64(y).reshape(-1), as_f64(inv)
+        mua = None if mu is None else as_f64(mu).reshape(-1)
+        out = np.empty(1)
+        self.check(self.lib.nmgp_mvn_logpdf(self.h, ptr(y), ptr(mua), float(logdet), ptr(inv), y.shape[0], ptr(out)))
+        return float(out[0])
+
+    def mvn_logpdf_kron(self, y, mu, B, K, sigma2, dense=False):
+        y, B, K = as_f64(y).reshape(-1), as_f64(B), as_f64(K)
+        mua = None if mu is None else as_f64(mu).reshape(-1)
+        out = np.empty(1)
+        fn = self.lib.nmgp_mvn_logpdf_dense if dense else self.lib.nmgp_mvn_logpdf_kron
+        self.check(fn(self.h, ptr(y), ptr(mua), ptr(B), B.shape[0], ptr(K), K.shape[0], float(sigma2), ptr(out)))
+        return float(out[0])
+
+    def kron_inv_logdet(self, sigma2, B, K, want_inv=True):
+        B, K = as_f64(B), as_f64(K)
+        n = B.shape[0] * K.shape[0]
+        inv = np.empty((n, n)) if want_inv else None
+        ld = np.empty(1)
+        self.check(self.lib.nmgp_kron_inv_logdet(self.h, float(sigma2), ptr(B), B.shape[0], ptr(K), K.shape[0], ptr(inv),
+                                                 ptr(ld)))
+        return inv, float(ld[0])
+
+    # -- prediction -----------------------------------------------------------------------------
+    def predict_svc(self, pars, hyper, xs):
+        pars, hyper, xs = as_f64(pars).reshape(-1), as_f64(hyper), as_f64(xs).reshape(-1)
+        S = xs.shape[0]
+        mean, var, Ls = np.empty((S, self.M)), np.empty((S, self.M)), np.empty((S, self.T))
+        self.check(self.lib.nmgp_predict_svc(self.h, ptr(pars), ptr(hyper), ptr(xs), S, ptr(mean), ptr(var), ptr(Ls)))
+        return mean, var, Ls
+
+    def predict_sep(self, pars, hyper, xs):
+        pars, hyper, xs = as_f64(pars).reshape(-1), as_f64(hyper), as_f64(xs).reshape(-1)
+        S = xs.shape[0]
+        mean, var = np.empty((S, self.M)), np.empty((S, self.M))
+        self.check(self.lib.nmgp_predict_sep(self.h, ptr(pars), ptr(hyper), ptr(xs), S, ptr(mean), ptr(var)))
+        return mean, var
+
+    def predict_sta(self, pars, xs):
+        pars, xs = as_f64(pars).reshape(-1), as_f64(xs).reshape(-1)
+        S = xs.shape[0]
+        mean, var = np.empty((S, self.M)), np.empty((S, self.M))
+        self.check(self.lib.nmgp_predict_sta(self.h, ptr(pars), ptr(xs), S, ptr(mean), ptr(var)))
+        return mean, var
+
+    # -- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self.check(self.lib.nmgp_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self.check(self.lib.nmgp_profile_reset(self.h))
+
+    def profile_read(self):
+        ms = np.zeros(len(STAGES))
+        cnt = np.zeros(len(STAGES), dtype=np.int64)
+        self.check(self.lib.nmgp_profile_read(self.h, ptr(ms), cnt.ctypes.data_as(c_ll_p)))
+        return {s: (float(ms[k]), int(cnt[k])) for k, s in enumerate(STAGES)}
+
+    def measure_hbm_gbs(self, nbytes=1 << 30, reps=10):
+        out = np.empty(1)
+        self.check(self.lib.nmgp_measure_hbm_gbs(self.h, int(nbytes), int(reps), ptr(out)))
+        return float(out[0])
+
+    def measure_dgemm_tflops(self, n=4096, reps=5):
+        out = np.empty(1)
+        self.check(self.lib.nmgp_measure_dgemm_tflops(self.h, int(n), int(reps), ptr(out)))
+        return float(out[0])
+
+
+def default_device():
+    """GPU ordinal for this process: NMGP_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    for k in ("NMGP_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(k)
+        if v is not None and v != "":
+            return int(v)
+    return 0
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context used by the `Utility` mirror (created on first use)."""
+    if device is None:
+        device = default_device()
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,632 @@
+// C ABI of libnmgp_hip.so: context, data residency, the nonseparable objective (value + gradient),
+// primitives, profiling.  See include/nmgp.h for the contract and the reference lines each entry replaces.
+#include <cstdarg>
+
+#include "nmgp_internal.h"
+
+using namespace nmgpk;
+
+// layout of the small device scalar block
+enum {
+    SC_LOGDET = 0,
+    SC_QUAD = 1,
+    SC_PRIORQ = 2,    // 1 + T entries (T <= 36)
+    SC_TRACE = 40,    // 2 entries
+    SC_OUT = 48,      // 8 entries
+    SC_MISC = 56,
+    SC_COUNT = 128
+};
+
+int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+struct StageScope {
+    nmgp_ctx* c;
+    int stage;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageScope(nmgp_ctx* ctx, int st) : c(ctx), stage(st) {
+        if (!c->profiling) return;
+        StageTimer& t = c->timers[stage];
+        if (!t.pool.empty()) {
+            e0 = t.pool.back().first;
+            e1 = t.pool.back().second;
+            t.pool.pop_back();
+        } else {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+        }
+        hipEventRecord(e0, c->stream);
+    }
+    ~StageScope() {
+        if (!c->profiling || !e0) return;
+        hipEventRecord(e1, c->stream);
+        c->timers[stage].pending.push_back({e0, e1});
+    }
+};
+
+static void profile_collect(nmgp_ctx* c) {
+    for (int s = 0; s < NMGP_STAGE_COUNT; ++s) {
+        StageTimer& t = c->timers[s];
+        for (auto& pr : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                t.ms += ms;
+                t.count += 1;
+            }
+            t.pool.push_back(pr);
+        }
+        t.pending.clear();
+    }
+}
+
+// ---- memory helpers ---------------------------------------------------------------------------
+static int dev_alloc(nmgp_ctx* c, double** p, size_t nelem) {
+    if (*p) {
+        hipFree(*p);
+        *p = nullptr;
+    }
+    if (nelem == 0) nelem = 1;
+    hipError_t e = hipMalloc((void**)p, nelem * sizeof(double));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return nmgp_fail(c, NMGP_E_NOMEM, "hipMalloc of %zu bytes failed: %s", nelem * sizeof(double),
+                         hipGetErrorString(e));
+    }
+    return 0;
+}
+
+static int scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
+    DevBuf& b = c->scratch[slot];
+    if (b.cap < nelem || !b.p) {
+        NMGP_TRY(dev_alloc(c, &b.p, nelem));
+        b.cap = nelem;
+    }
+    *out = b.p;
+    return 0;
+}
+
+static void free_priors(nmgp_ctx* c) {
+    for (auto& p : c->priors) {
+        if (p.L) hipFree(p.L);
+        if (p.logdet) hipFree(p.logdet);
+    }
+    c->priors.clear();
+}
+
+static void free_subject(nmgp_ctx* c) {
+    double** ptrs[] = {&c->d_x, &c->d_Y, &c->d_y, &c->d_pars, &c->d_grad, &c->d_ell, &c->d_sig, &c->d_Lv,
+                       &c->d_S, &c->d_z, &c->d_alpha, &c->d_R, &c->d_R2, &c->d_part, &c->d_K, &c->d_K2,
+                       &c->d_w, &c->d_E};
+    for (double** p : ptrs) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    c->S_cap = c->K_cap = c->part_cap = 0;
+    free_priors(c);
+}
+
+// ---- context -----------------------------------------------------------------------------------
+extern "C" int nmgp_version(void) { return NMGP_VERSION; }
+
+extern "C" int nmgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
+    if (!out) return NMGP_E_NULL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NMGP_E_HIP;
+    if (device < 0 || device >= ndev) return NMGP_E_SHAPE;
+    nmgp_ctx* c = new nmgp_ctx();
+    c->device = device;
+    *out = c;   // returned even on failure below so that nmgp_last_error() is reachable
+    HIP_TRY(c, hipSetDevice(device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    BLAS_TRY(c, rocblas_create_handle(&c->blas));
+    BLAS_TRY(c, rocblas_set_stream(c->blas, c->stream));
+    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+    NMGP_TRY(dev_alloc(c, &c->d_scal, SC_COUNT));
+    HIP_TRY(c, hipMalloc((void**)&c->d_info, 8 * sizeof(int)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, SC_COUNT * sizeof(double)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_info, 8 * sizeof(int)));
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 8 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, SC_COUNT * sizeof(double), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nmgp_ctx_destroy(nmgp_ctx* c) {
+    if (!c) return NMGP_E_NULL;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_subject(c);
+    for (auto& b : c->scratch)
+        if (b.p) hipFree(b.p);
+    for (auto& t : c->timers) {
+        for (auto& pr : t.pending) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        for (auto& pr : t.pool) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    }
+    if (c->d_scal) hipFree(c->d_scal);
+    if (c->d_info) hipFree(c->d_info);
+    if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->h_info) hipHostFree(c->h_info);
+    if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" const char* nmgp_last_error(const nmgp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int nmgp_sync(nmgp_ctx* c) {
+    if (!c) return NMGP_E_NULL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- data residency ----------------------------------------------------------------------------
+extern "C" int nmgp_set_data(nmgp_ctx* c, const double* x, const double* Y, int N, int M) {
+    if (!c) return NMGP_E_NULL;
+    if (!x || !Y) return nmgp_fail(c, NMGP_E_NULL, "nmgp_set_data: x and Y must not be NULL");
+    if (N <= 0 || M <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "nmgp_set_data: N=%d, M=%d must be positive", N, M);
+    if (M > NMGP_MAX_OUTPUTS)
+        return nmgp_fail(c, NMGP_E_UNSUPPORTED, "nmgp_set_data: M=%d exceeds NMGP_MAX_OUTPUTS=%d", M, NMGP_MAX_OUTPUTS);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_subject(c);
+    c->N = N;
+    c->M = M;
+    c->T = M * (M + 1) / 2;
+    c->n = N * M;
+    const size_t Ns = N, T = c->T, n = c->n;
+    c->P_svc = (long long)(Ns * (1 + T) + 1);
+    size_t Pmax = Ns * (1 + T) + 1;
+    if (2 * Ns + T + 1 > Pmax) Pmax = 2 * Ns + T + 1;
+    NMGP_TRY(dev_alloc(c, &c->d_x, Ns));
+    NMGP_TRY(dev_alloc(c, &c->d_Y, n));
+    NMGP_TRY(dev_alloc(c, &c->d_y, n));
+    NMGP_TRY(dev_alloc(c, &c->d_pars, Pmax));
+    NMGP_TRY(dev_alloc(c, &c->d_grad, Pmax));
+    NMGP_TRY(dev_alloc(c, &c->d_ell, Ns));
+    NMGP_TRY(dev_alloc(c, &c->d_sig, Ns));
+    NMGP_TRY(dev_alloc(c, &c->d_Lv, Ns * T));
+    NMGP_TRY(dev_alloc(c, &c->d_z, n));
+    NMGP_TRY(dev_alloc(c, &c->d_alpha, n));
+    NMGP_TRY(dev_alloc(c, &c->d_R, Ns * (1 + T)));
+    NMGP_TRY(dev_alloc(c, &c->d_R2, Ns * (1 + T)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_x, x, Ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_Y, Y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    transpose_y(c->stream, c->d_Y, N, M, c->d_y);
+    HIP_TRY(c, hipMemsetAsync(c->d_pars, 0, Pmax * sizeof(double), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int ensure_S(nmgp_ctx* c) {
+    const size_t n = c->n;
+    if (!c->d_S || c->S_cap < n * n) {
+        NMGP_TRY(dev_alloc(c, &c->d_S, n * n));
+        c->S_cap = n * n;
+    }
+    c->ldS = c->n;
+    return 0;
+}
+
+// Cached Cholesky factor of RBF(x; alpha, beta) + jitter I (the GP-prior covariances of logpos.py:357,362).
+static int get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
+    for (auto& p : c->priors)
+        if (p.alpha == alpha && p.beta == beta) {
+            *out = &p;
+            return 0;
+        }
+    PriorFactor pf;
+    pf.alpha = alpha;
+    pf.beta = beta;
+    const size_t Ns = c->N;
+    NMGP_TRY(dev_alloc(c, &pf.L, Ns * Ns));
+    if (dev_alloc(c, &pf.logdet, 1) != 0) {
+        hipFree(pf.L);
+        return NMGP_E_NOMEM;
+    }
+    rbf_cov_sym(c->stream, c->d_x, c->N, alpha, beta, pf.L, c->N, false);
+    rocblas_status st = rocsolver_dpotrf(c->blas, rocblas_fill_lower, c->N, pf.L, c->N, c->d_info + 1);
+    half_logdet(c->stream, pf.L, c->N, c->N, pf.logdet);
+    hipMemcpyAsync(c->h_info + 1, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (st != rocblas_status_success || e != hipSuccess || c->h_info[1] != 0) {
+        int info = c->h_info[1];
+        hipFree(pf.L);
+        hipFree(pf.logdet);
+        if (st != rocblas_status_success || e != hipSuccess)
+            return nmgp_fail(c, NMGP_E_HIP, "prior factorisation failed (rocblas_status %d, %s)", (int)st,
+                             hipGetErrorString(e));
+        return nmgp_fail(c, info, "GP prior covariance RBF(alpha=%g, beta=%g)+jitter is not positive definite "
+                         "(leading minor %d)", alpha, beta, info);
+    }
+    c->priors.push_back(pf);
+    *out = &c->priors.back();
+    return 0;
+}
+
+// ---- nonseparable objective --------------------------------------------------------------------
+static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_grad) {
+    if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
+    if (!hyper) return nmgp_fail(c, NMGP_E_NULL, "hyper must not be NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    NMGP_TRY(ensure_S(c));
+    const int N = c->N, M = c->M, T = c->T, n = c->n, ld = c->ldS;
+    const long long P = c->P_svc;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
+    const double a = hyper[6], b = hyper[7];
+    hipStream_t s = c->stream;
+    double* sc = c->d_scal;
+    // priors first: the factor pointers may be created (and synchronised) here
+    PriorFactor *pl = nullptr, *pL = nullptr;
+    NMGP_TRY(get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(get_prior(c, al_L, be_L, &pL));
+    // get_prior may have grown c->priors: re-resolve the first pointer
+    NMGP_TRY(get_prior(c, al_l, be_l, &pl));
+    if (want_grad) {
+        const size_t NJ = (N + 63) / 64;
+        const size_t need = NJ * (size_t)N * (T + 1);
+        if (!c->d_part || c->part_cap < need) {
+            NMGP_TRY(dev_alloc(c, &c->d_part, need));
+            c->part_cap = need;
+        }
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    {
+        StageScope sp(c, NMGP_STAGE_COV);
+        svc_prep(s, c->d_pars, N, M, c->d_ell, c->d_Lv);
+        int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (P - 1), c->d_S, ld, N, M, false);
+        if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_CHOL);
+        BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info));
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_SOLVE);
+        HIP_TRY(c, hipMemcpyAsync(c->d_z, c->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n,
+                                  c->d_S, ld, c->d_z, 1));
+        if (want_grad) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
+                                      rocblas_diagonal_non_unit, n, c->d_S, ld, c->d_alpha, 1));
+        }
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_REDUCE);
+        chol_logdet_quad(s, c->d_S, ld, n, c->d_z, sc + SC_LOGDET, sc + SC_QUAD);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_PRIOR);
+        const double one = 1.0;
+        svc_prior_rhs(s, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
+        if (pl == pL) {
+            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                      rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, N, c->d_R, N));
+        } else {
+            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                      rocblas_diagonal_non_unit, N, 1, &one, pl->L, N, c->d_R, N));
+            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                      rocblas_diagonal_non_unit, N, T, &one, pL->L, N, c->d_R + N, N));
+        }
+        col_sumsq(s, c->d_R, N, N, 1 + T, sc + SC_PRIORQ);
+        if (want_grad && prior) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_R2, c->d_R, (size_t)N * (1 + T) * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (pl == pL) {
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                          rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, N, c->d_R2, N));
+            } else {
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, N, c->d_R2, N));
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, N, c->d_R2 + N, N));
+            }
+        }
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_REDUCE);
+        const double ig_const = a * std::log(b) - std::lgamma(a);   // distributions.py:134
+        svc_finalize(s, sc + SC_LOGDET, sc + SC_QUAD, sc + SC_PRIORQ, pl->logdet, pL->logdet, c->d_pars, P, N, T, a, b,
+                     ig_const, prior, sc + SC_OUT);
+    }
+    if (want_grad) {
+        {
+            StageScope sp(c, NMGP_STAGE_INVERSE);
+            BLAS_TRY(c, rocsolver_dpotri(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info + 2));
+            fill_lower_to_full(s, c->d_S, ld, n);
+        }
+        {
+            StageScope sp(c, NMGP_STAGE_ADJOINT);
+            trace_terms(s, c->d_alpha, c->d_S, ld, n, sc + SC_TRACE);
+            int r = svc_adjoint(s, c->d_x, c->d_ell, c->d_Lv, c->d_alpha, c->d_S, ld, N, M, c->d_part);
+            if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
+            svc_grad_final(s, c->d_part, (N + 63) / 64, N, M, c->d_Lv, c->d_R2, N, c->d_pars, sc + SC_TRACE, a, b,
+                           prior, c->d_grad);
+        }
+    }
+    c->last_want_grad = want_grad != 0;
+    c->last_kind = 1;
+    return 0;
+}
+
+extern "C" int nmgp_svc_set_pars(nmgp_ctx* c, const double* pars) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars) return nmgp_fail(c, NMGP_E_NULL, "pars must not be NULL");
+    if (!c->d_pars) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_pars, pars, (size_t)c->P_svc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+extern "C" double* nmgp_svc_pars_dev(nmgp_ctx* c) { return c ? c->d_pars : nullptr; }
+extern "C" double* nmgp_svc_grad_dev(nmgp_ctx* c) { return c ? c->d_grad : nullptr; }
+
+extern "C" int nmgp_svc_eval_resident(nmgp_ctx* c, const double hyper[8], int prior, int want_grad) {
+    if (!c) return NMGP_E_NULL;
+    return svc_enqueue(c, hyper, prior, want_grad);
+}
+
+extern "C" int nmgp_svc_fetch(nmgp_ctx* c, double out5[5], double* grad) {
+    if (!c) return NMGP_E_NULL;
+    if (c->last_kind != 1) return nmgp_fail(c, NMGP_E_STATE, "no nonseparable evaluation is pending");
+    if (grad && !c->last_want_grad)
+        return nmgp_fail(c, NMGP_E_STATE, "gradient requested but the last evaluation ran with want_grad=0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin, c->d_scal + SC_OUT, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_info, c->d_info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (grad)
+        HIP_TRY(c, hipMemcpyAsync(grad, c->d_grad, (size_t)c->P_svc * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_info[0] != 0)
+        return nmgp_fail(c, c->h_info[0], "Cholesky of the %d x %d covariance failed: leading minor %d is not positive "
+                         "definite", c->n, c->n, c->h_info[0]);
+    if (out5)
+        for (int k = 0; k < 5; ++k) out5[k] = c->h_pin[k];
+    if (!std::isfinite(c->h_pin[0]) || !std::isfinite(c->h_pin[1]))
+        return nmgp_fail(c, NMGP_NUM_NAN, "non-finite log posterior (NegLog=%g, loglik=%g)", c->h_pin[0], c->h_pin[1]);
+    return 0;
+}
+
+extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyper[8], int prior, double out5[5],
+                               double* grad) {
+    if (!c) return NMGP_E_NULL;
+    if (!out5) return nmgp_fail(c, NMGP_E_NULL, "out5 must not be NULL");
+    NMGP_TRY(nmgp_svc_set_pars(c, pars));
+    NMGP_TRY(svc_enqueue(c, hyper, prior, grad != nullptr));
+    return nmgp_svc_fetch(c, out5, grad);
+}
+
+extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!out) return nmgp_fail(c, NMGP_E_NULL, "out must not be NULL");
+    NMGP_TRY(nmgp_svc_set_pars(c, pars));
+    NMGP_TRY(ensure_S(c));
+    hipStream_t s = c->stream;
+    svc_prep(s, c->d_pars, c->N, c->M, c->d_ell, c->d_Lv);
+    int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (c->P_svc - 1), c->d_S, c->ldS, c->N, c->M, true);
+    if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", c->M);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_S, (size_t)c->n * c->n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- primitives --------------------------------------------------------------------------------
+static int upload(nmgp_ctx* c, int slot, const double* h, size_t nelem, double** d) {
+    NMGP_TRY(scratch_get(c, slot, nelem, d));
+    HIP_TRY(c, hipMemcpyAsync(*d, h, nelem * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int download(nmgp_ctx* c, double* h, const double* d, size_t nelem) {
+    HIP_TRY(c, hipMemcpyAsync(h, d, nelem * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int nmgp_pairwise_distances(nmgp_ctx* c, const double* x1, int n1, const double* x2, int n2, int d,
+                                       double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!x1 || !out) return nmgp_fail(c, NMGP_E_NULL, "x1/out must not be NULL");
+    if (!x2) n2 = n1;
+    if (n1 <= 0 || n2 <= 0 || d <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape n1=%d n2=%d d=%d", n1, n2, d);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *dx1, *dx2, *dout;
+    NMGP_TRY(upload(c, 0, x1, (size_t)n1 * d, &dx1));
+    if (x2) NMGP_TRY(upload(c, 1, x2, (size_t)n2 * d, &dx2)); else dx2 = dx1;
+    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    pairwise_rect(c->stream, dx1, n1, dx2, n2, d, dout);
+    return download(c, out, dout, (size_t)n1 * n2);
+}
+
+extern "C" int nmgp_rbf_cov(nmgp_ctx* c, const double* x1, int n1, const double* x2, int n2, int d, double alpha,
+                            double beta, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!x1 || !out) return nmgp_fail(c, NMGP_E_NULL, "x1/out must not be NULL");
+    if (!x2) n2 = n1;
+    if (n1 <= 0 || n2 <= 0 || d <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape n1=%d n2=%d d=%d", n1, n2, d);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *dx1, *dx2, *dout;
+    NMGP_TRY(upload(c, 0, x1, (size_t)n1 * d, &dx1));
+    if (x2) NMGP_TRY(upload(c, 1, x2, (size_t)n2 * d, &dx2)); else dx2 = dx1;
+    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    rbf_cov_rect(c->stream, dx1, n1, dx2, n2, d, alpha, beta, x2 == nullptr, dout);
+    return download(c, out, dout, (size_t)n1 * n2);
+}
+
+extern "C" int nmgp_nonstat_rbf_cov(nmgp_ctx* c, const double* x1, const double* s1, const double* l1, int n1,
+                                    const double* x2, const double* s2, const double* l2, int n2, int d, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!x1 || !out) return nmgp_fail(c, NMGP_E_NULL, "x1/out must not be NULL");
+    if (!x2) n2 = n1;
+    if (n1 <= 0 || n2 <= 0 || d <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape n1=%d n2=%d d=%d", n1, n2, d);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *dx1, *dx2, *ds1 = nullptr, *dl1 = nullptr, *ds2 = nullptr, *dl2 = nullptr, *dout;
+    // one upload buffer per operand: slots 0..4 hold [x1 | s1 | l1], [x2 | s2 | l2]
+    double* b1;
+    NMGP_TRY(scratch_get(c, 0, (size_t)n1 * (d + 2), &b1));
+    dx1 = b1;
+    HIP_TRY(c, hipMemcpyAsync(dx1, x1, (size_t)n1 * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (s1) {
+        ds1 = b1 + (size_t)n1 * d;
+        HIP_TRY(c, hipMemcpyAsync(ds1, s1, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (l1) {
+        dl1 = b1 + (size_t)n1 * (d + 1);
+        HIP_TRY(c, hipMemcpyAsync(dl1, l1, (size_t)n1 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (x2) {
+        double* b2;
+        NMGP_TRY(scratch_get(c, 1, (size_t)n2 * (d + 2), &b2));
+        dx2 = b2;
+        HIP_TRY(c, hipMemcpyAsync(dx2, x2, (size_t)n2 * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (s2) {
+            ds2 = b2 + (size_t)n2 * d;
+            HIP_TRY(c, hipMemcpyAsync(ds2, s2, (size_t)n2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        if (l2) {
+            dl2 = b2 + (size_t)n2 * (d + 1);
+            HIP_TRY(c, hipMemcpyAsync(dl2, l2, (size_t)n2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+    } else {
+        dx2 = dx1;
+        ds2 = ds1;
+        dl2 = dl1;
+    }
+    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    gibbs_cov_rect(c->stream, dx1, ds1, dl1, n1, dx2, ds2, dl2, n2, d, x2 == nullptr, dout);
+    return download(c, out, dout, (size_t)n1 * n2);
+}
+
+extern "C" int nmgp_kron_product(nmgp_ctx* c, const double* a, int ar, int ac, const double* b, int br, int bc,
+                                 double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!a || !b || !out) return nmgp_fail(c, NMGP_E_NULL, "a/b/out must not be NULL");
+    if (ar <= 0 || ac <= 0 || br <= 0 || bc <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *da, *db, *dout;
+    NMGP_TRY(upload(c, 0, a, (size_t)ar * ac, &da));
+    NMGP_TRY(upload(c, 1, b, (size_t)br * bc, &db));
+    const size_t tot = (size_t)ar * ac * br * bc;
+    NMGP_TRY(scratch_get(c, 5, tot, &dout));
+    kron_product(c->stream, da, ar, ac, db, br, bc, dout);
+    return download(c, out, dout, tot);
+}
+
+// ---- profiling / micro-benchmarks ----------------------------------------------------------------
+extern "C" int nmgp_profile_enable(nmgp_ctx* c, int on) {
+    if (!c) return NMGP_E_NULL;
+    c->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int nmgp_profile_reset(nmgp_ctx* c) {
+    if (!c) return NMGP_E_NULL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    profile_collect(c);
+    for (auto& t : c->timers) {
+        t.ms = 0;
+        t.count = 0;
+    }
+    return 0;
+}
+
+extern "C" int nmgp_profile_read(nmgp_ctx* c, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT]) {
+    if (!c) return NMGP_E_NULL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    profile_collect(c);
+    for (int s = 0; s < NMGP_STAGE_COUNT; ++s) {
+        if (ms) ms[s] = c->timers[s].ms;
+        if (count) count[s] = c->timers[s].count;
+    }
+    return 0;
+}
+
+extern "C" int nmgp_measure_hbm_gbs(nmgp_ctx* c, long long bytes, int reps, double* gbs) {
+    if (!c) return NMGP_E_NULL;
+    if (!gbs) return nmgp_fail(c, NMGP_E_NULL, "gbs must not be NULL");
+    if (bytes < 1024 || reps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bytes/reps too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nelem = ((size_t)bytes / 16) * 2;
+    double *src, *dst;
+    NMGP_TRY(scratch_get(c, 3, nelem, &src));
+    NMGP_TRY(scratch_get(c, 4, nelem, &dst));
+    HIP_TRY(c, hipMemsetAsync(src, 0, nelem * sizeof(double), c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    stream_copy(c->stream, src, dst, nelem);
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) stream_copy(c->stream, src, dst, nelem);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbs = 2.0 * (double)nelem * 8.0 * reps / (ms * 1e-3) / 1e9;   // read + write
+    return 0;
+}
+
+extern "C" int nmgp_measure_dgemm_tflops(nmgp_ctx* c, int n, int reps, double* tflops) {
+    if (!c) return NMGP_E_NULL;
+    if (!tflops) return nmgp_fail(c, NMGP_E_NULL, "tflops must not be NULL");
+    if (n <= 0 || reps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "n/reps must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)n * n;
+    double *A, *B, *C;
+    NMGP_TRY(scratch_get(c, 2, nn, &A));
+    NMGP_TRY(scratch_get(c, 3, nn, &B));
+    NMGP_TRY(scratch_get(c, 4, nn, &C));
+    // pseudo-random, non-trivial operands (zero-filled operands over-state the sustainable clock)
+    std::vector<double> h(nn);
+    unsigned long long st = 88172645463325252ull;
+    for (size_t k = 0; k < nn; ++k) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        h[k] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+    }
+    HIP_TRY(c, hipMemcpy(A, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(B, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    const double one = 1.0, zero = 0.0;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, A, n, B, n,
+                              &zero, C, n));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r)
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, A, n, B,
+                                  n, &zero, C, n));
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *tflops = 2.0 * (double)n * n * n * reps / (ms * 1e-3) / 1e12;
+    return 0;
+}

@@ -1,0 +1,151 @@
+// Internal declarations of libnmgp_hip.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "nmgp.h"
+
+#define NMGP_JITTER 1e-6     // Utility/settings.py:3
+#define NMGP_PRECISION 1e-6  // Utility/settings.py:6
+
+struct DevBuf {
+    double* p = nullptr;
+    size_t cap = 0;  // elements
+};
+
+// Cholesky factor of an N x N GP-prior covariance RBF(x; alpha, beta) + jitter I, cached per (alpha, beta)
+// for the current x (logpos.py:357,362 rebuild and re-factorise it on every evaluation).
+struct PriorFactor {
+    double alpha = 0, beta = 0;
+    double* L = nullptr;       // N x N, lower, column-major
+    double* logdet = nullptr;  // device scalar: log det of the covariance
+};
+
+struct StageTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double ms = 0;
+    long long count = 0;
+};
+
+struct nmgp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    std::string err;
+
+    // subject data
+    int N = 0, M = 0, T = 0, n = 0;
+    double* d_x = nullptr;   // [N]
+    double* d_Y = nullptr;   // [N, M] row-major
+    double* d_y = nullptr;   // [n] output-major
+    // nonseparable state
+    long long P_svc = 0;
+    double* d_pars = nullptr;   // [P]  (largest of the three parameter layouts)
+    double* d_grad = nullptr;   // [P]
+    double* d_ell = nullptr;    // [N]    exp(tilde_l)
+    double* d_sig = nullptr;    // [N]    exp(tilde_sigma) (separable)
+    double* d_Lv = nullptr;     // [N, T] packed tril factors, exp applied on the diagonal slots
+    double* d_S = nullptr;      // [n, n] covariance / factor / inverse (lower, column-major)
+    size_t S_cap = 0;
+    int ldS = 0;
+    double* d_z = nullptr;      // [n]   L^-1 y, then alpha = Sigma^-1 y
+    double* d_alpha = nullptr;  // [n]
+    double* d_R = nullptr;      // [N, 1+T] prior right-hand sides / solutions (column-major)
+    double* d_R2 = nullptr;     // [N, 1+T] Sigma_prior^-1 r
+    double* d_scal = nullptr;   // small device scalars (see SC_* in nmgp_api.hip)
+    double* d_part = nullptr;   // partial sums of the adjoint pass
+    size_t part_cap = 0;
+    int* d_info = nullptr;      // rocSOLVER status words
+    double* h_pin = nullptr;    // pinned host staging (scalars)
+    int* h_info = nullptr;
+    // generic scratch for the primitive entry points
+    DevBuf scratch[6];
+    std::vector<PriorFactor> priors;
+    // eigen path
+    double* d_K = nullptr;      // [N, N] K_x then eigenvectors (separable / stationary)
+    double* d_K2 = nullptr;     // [N, N] second N x N workspace
+    size_t K_cap = 0;
+    double* d_w = nullptr;      // [N] eigenvalues of K_x
+    double* d_E = nullptr;      // [N] syevd workspace
+    bool last_want_grad = false;
+    int last_kind = 0;          // 1 svc
+
+    bool profiling = false;
+    StageTimer timers[NMGP_STAGE_COUNT];
+};
+
+int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return nmgp_fail(ctx, NMGP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define BLAS_TRY(ctx, expr)                                                                       \
+    do {                                                                                          \
+        rocblas_status s__ = (expr);                                                              \
+        if (s__ != rocblas_status_success)                                                        \
+            return nmgp_fail(ctx, NMGP_E_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)s__, \
+                             __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define NMGP_TRY(expr)          \
+    do {                        \
+        int r__ = (expr);       \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+// ---- kernel launchers (nmgp_kernels.hip) -------------------------------------------------------
+namespace nmgpk {
+
+// parameter unpacking: ell = exp(tilde_l), Lv = tril factors with exp on the diagonal slots
+void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv);
+// kernel #1: fused nonseparable covariance (lower triangle, column-major, output-major indices)
+int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
+                  double* S, int ld, int N, int M, bool full);
+// symmetric N x N builds (lower triangle unless full)
+void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full);
+void gibbs_cov_sym(hipStream_t s, const double* x, const double* sig, const double* ell, int N, double* out, int ld,
+                   bool full);
+// rectangular d-dimensional primitives, row-major output [n1, n2]
+void pairwise_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double* out);
+void rbf_cov_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double alpha, double beta,
+                  bool sym, double* out);
+void gibbs_cov_rect(hipStream_t s, const double* x1, const double* s1, const double* l1, int n1, const double* x2,
+                    const double* s2, const double* l2, int n2, int d, bool sym, double* out);
+void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* b, int br, int bc, double* out);
+// reductions
+void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
+                      double* out_quad);
+void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out);
+void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out);
+void fill_lower_to_full(hipStream_t s, double* A, int ld, int n);
+void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
+void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld);
+void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
+int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
+                const double* Sinv, int ld, int N, int M, double* part);
+void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out);
+void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
+                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad);
+void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
+                  const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
+                  double ig_const, int prior, double* out5);
+void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out);
+
+}  // namespace nmgpk

@@ -1,0 +1,632 @@
+// Hand-written gfx950 kernels of the log-posterior path: covariance builds, Kronecker expansion,
+// reductions.  All arithmetic is IEEE float64; the build uses -ffp-contract=off so that the element
+// formulas round exactly like the reference's unfused torch-CPU elementwise ops (kernels.py:20,68-72).
+//
+// Matrices handed to rocSOLVER/rocBLAS are column-major with the LOWER triangle stored; because every
+// such matrix is symmetric this is the same memory image as the reference's row-major upper triangle.
+#include "nmgp_internal.h"
+
+namespace nmgpk {
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (64-lane wavefronts)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block of up to 1024 threads (16 waves); result valid in thread 0
+__device__ inline double block_sum(double v, double* sh /*[16]*/) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    int nw = (blockDim.x + 63) >> 6;
+    v = (threadIdx.x < nw) ? sh[threadIdx.x] : 0.0;
+    if (w == 0) v = wave_sum(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter unpacking (utils.py:10-22,38-46: exp on the tril-diagonal slots; logpos.py:342: l = exp(tilde_l))
+// ---------------------------------------------------------------------------------------------
+__global__ void k_svc_prep(const double* __restrict__ pars, int N, int M, int T, double* __restrict__ ell,
+                           double* __restrict__ Lv) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    ell[i] = exp(pars[i]);
+    const double* u = pars + N + (size_t)i * T;
+    double* o = Lv + (size_t)i * T;
+    int t = 0;
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c <= r; ++c, ++t) o[t] = (c == r) ? exp(u[t]) : u[t];
+}
+
+void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv) {
+    int T = M * (M + 1) / 2;
+    hipLaunchKernelGGL(k_svc_prep, dim3(cdiv(N, 256)), dim3(256), 0, s, pars, N, M, T, ell, Lv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel #1: fused nonseparable covariance
+//   S[m N + i, m' N + j] = (K0(i,j) + jitter d_ij) * sum_r L_i[m,r] L_j[m',r]  + sigma2 d_(mi)(m'j)
+// replaces kernels.Nonstationary_RBF_cov (kernels.py:46-73), generate_K_index_SVC (logpos.py:111-118),
+// the n-major -> m-major gathers (logpos.py:347-348), kronecker_product(ones, K_x) * K_i (logpos.py:349)
+// and "+ sigma2_err * eye" (logpos.py:352).  One 64 x 64 tile of locations per workgroup; the j-side
+// coordinates / length-scales / factors are staged in LDS and broadcast, the i-side lives in registers;
+// lanes run along i so that every wave store is 512 contiguous bytes of one column.
+// Only the lower triangle is written unless FULL.
+// ---------------------------------------------------------------------------------------------
+template <int M, bool FULL>
+__global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, const double* __restrict__ ell,
+                                                  const double* __restrict__ Lv, const double* __restrict__ tse,
+                                                  double* __restrict__ S, int ld, int N) {
+    constexpr int T = M * (M + 1) / 2;
+    constexpr int TJ = 64;
+    __shared__ double sx[TJ], sl[TJ], sL[TJ * T];
+    const int I = blockIdx.x, J = blockIdx.y;
+    if (!FULL && M == 1 && I < J) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j0 = J * TJ;
+    if (tid < TJ) {
+        int j = j0 + tid;
+        sx[tid] = (j < N) ? x[j] : 0.0;
+        sl[tid] = (j < N) ? ell[j] : 1.0;
+    }
+    for (int k = tid; k < TJ * T; k += 256) {
+        size_t g = (size_t)j0 * T + k;
+        sL[k] = (g < (size_t)N * T) ? Lv[g] : 0.0;
+    }
+    __syncthreads();
+    const int i = I * 64 + lane;
+    if (i >= N) return;
+    const double sigma2 = exp(tse[0]);
+    const double xi = x[i], li = ell[i];
+    const double xi2 = xi * xi, li2 = li * li;
+    double Li[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) Li[t] = Lv[(size_t)i * T + t];
+    const size_t Ns = (size_t)N;
+#pragma unroll 2
+    for (int jj = 0; jj < TJ / 4; ++jj) {
+        const int k = w * (TJ / 4) + jj;
+        const int j = j0 + k;
+        if (j >= N) break;
+        const double xj = sx[k], lj = sl[k];
+        const double dist = (xi2 + xj * xj) - 2.0 * (xi * xj);   // kernels.py:20
+        const double A = li2 + lj * lj;                          // kernels.py:69
+        double kv = sqrt(2.0 * (li * lj) / A) * exp(-dist / A);  // kernels.py:70,72 (sigma == 1)
+        if (i == j) kv = NMGP_JITTER + kv;                       // kernels.py:64
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+#pragma unroll
+            for (int mp = 0; mp < M; ++mp) {
+                if (!FULL) {
+                    if (mp > m) continue;
+                    if (mp == m && i < j) continue;
+                }
+                double b = 0.0;
+                const int rmax = (m < mp) ? m : mp;
+#pragma unroll
+                for (int r = 0; r <= rmax; ++r) b += Li[m * (m + 1) / 2 + r] * sL[k * T + mp * (mp + 1) / 2 + r];
+                double v = kv * b;
+                if (m == mp && i == j) v += sigma2;
+                S[((size_t)mp * Ns + j) * ld + ((size_t)m * Ns + i)] = v;
+            }
+        }
+    }
+}
+
+template <int M>
+static void launch_svc_cov(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
+                           double* S, int ld, int N, bool full) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+    if (full)
+        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N);
+    else
+        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N);
+}
+
+int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse, double* S,
+                  int ld, int N, int M, bool full) {
+    switch (M) {
+        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        default: return NMGP_E_UNSUPPORTED;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// symmetric N x N kernels on 1-D inputs (GP priors, separable K_x); column-major == row-major (symmetric)
+// ---------------------------------------------------------------------------------------------
+template <bool GIBBS, bool FULL>
+__global__ __launch_bounds__(256) void k_cov_sym(const double* __restrict__ x, const double* __restrict__ sig,
+                                                  const double* __restrict__ ell, int N, double alpha, double beta,
+                                                  double* __restrict__ out, int ld) {
+    constexpr int TJ = 64;
+    __shared__ double sx[TJ], sl[TJ], ss[TJ];
+    const int I = blockIdx.x, J = blockIdx.y;
+    if (!FULL && I < J) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j0 = J * TJ;
+    if (tid < TJ) {
+        int j = j0 + tid;
+        double xv = (j < N) ? x[j] : 0.0;
+        sx[tid] = GIBBS ? xv : xv / beta;                      // kernels.py:38-39 (inputs scaled by 1/beta)
+        sl[tid] = (GIBBS && j < N) ? ell[j] : 1.0;
+        ss[tid] = (GIBBS && sig != nullptr && j < N) ? sig[j] : 1.0;
+    }
+    __syncthreads();
+    const int i = I * 64 + lane;
+    if (i >= N) return;
+    const double xi = GIBBS ? x[i] : x[i] / beta;
+    const double li = GIBBS ? ell[i] : 1.0;
+    const double si = (GIBBS && sig != nullptr) ? sig[i] : 1.0;
+    const double xi2 = xi * xi, li2 = li * li;
+    const double a2 = alpha * alpha;
+    for (int jj = 0; jj < TJ / 4; ++jj) {
+        const int k = w * (TJ / 4) + jj;
+        const int j = j0 + k;
+        if (j >= N) break;
+        if (!FULL && i < j) continue;
+        const double xj = sx[k];
+        const double dist = (xi2 + xj * xj) - 2.0 * (xi * xj);
+        double v;
+        if (GIBBS) {
+            const double lj = sl[k];
+            const double A = li2 + lj * lj;
+            v = (si * ss[k]) * sqrt(2.0 * (li * lj) / A) * exp(-dist / A);   // kernels.py:69-72
+        } else {
+            v = exp(-0.5 * dist) * a2;                                       // kernels.py:42
+        }
+        if (i == j) v = NMGP_JITTER + v;
+        out[(size_t)j * ld + i] = v;
+    }
+}
+
+void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+    if (full)
+        hipLaunchKernelGGL((k_cov_sym<false, true>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
+    else
+        hipLaunchKernelGGL((k_cov_sym<false, false>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
+}
+
+void gibbs_cov_sym(hipStream_t s, const double* x, const double* sig, const double* ell, int N, double* out, int ld,
+                   bool full) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+    if (full)
+        hipLaunchKernelGGL((k_cov_sym<true, true>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
+    else
+        hipLaunchKernelGGL((k_cov_sym<true, false>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rectangular d-dimensional primitives (row-major [n1, n2] output; lanes run along n2)
+//   MODE 0: pairwise_distances (kernels.py:5-21)   1: RBF_cov (24-43)   2: Nonstationary_RBF_cov (46-73)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rect(const double* __restrict__ x1, const double* __restrict__ s1,
+                                               const double* __restrict__ l1, int n1, const double* __restrict__ x2,
+                                               const double* __restrict__ s2, const double* __restrict__ l2, int n2,
+                                               int d, double alpha, double beta, int sym, double* __restrict__ out) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= n1 || j >= n2) return;
+    double xn = 0.0, yn = 0.0, dot = 0.0;
+    for (int k = 0; k < d; ++k) {
+        double a = x1[(size_t)i * d + k], b = x2[(size_t)j * d + k];
+        if (MODE == 1) { a = a / beta; b = b / beta; }
+        xn += a * a;
+        yn += b * b;
+        dot += a * b;
+    }
+    const double dist = (xn + yn) - 2.0 * dot;
+    double v;
+    if (MODE == 0) {
+        v = dist;
+    } else if (MODE == 1) {
+        v = exp(-0.5 * dist) * (alpha * alpha);
+        if (sym && i == j) v = NMGP_JITTER + v;
+    } else {
+        const double li = l1 ? l1[i] : 1.0, lj = l2 ? l2[j] : 1.0;
+        const double si = s1 ? s1[i] : 1.0, sj = s2 ? s2[j] : 1.0;
+        const double A = li * li + lj * lj;
+        v = (si * sj) * sqrt(2.0 * (li * lj) / A) * exp(-dist / A);
+        if (sym && i == j) v = NMGP_JITTER + v;
+    }
+    out[(size_t)i * n2 + j] = v;
+}
+
+void pairwise_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double* out) {
+    hipLaunchKernelGGL((k_rect<0>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
+                       nullptr, nullptr, n2, d, 1.0, 1.0, 0, out);
+}
+void rbf_cov_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double alpha, double beta,
+                  bool sym, double* out) {
+    hipLaunchKernelGGL((k_rect<1>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
+                       nullptr, nullptr, n2, d, alpha, beta, sym ? 1 : 0, out);
+}
+void gibbs_cov_rect(hipStream_t s, const double* x1, const double* s1, const double* l1, int n1, const double* x2,
+                    const double* s2, const double* l2, int n2, int d, bool sym, double* out) {
+    hipLaunchKernelGGL((k_rect<2>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, s1, l1, n1, x2, s2, l2, n2,
+                       d, 1.0, 1.0, sym ? 1 : 0, out);
+}
+
+// kronecker_operation.kronecker_product (kronecker_operation.py:5-22): out[(p*br+r), (q*bc+c)] = a[p,q] b[r,c]
+__global__ __launch_bounds__(256) void k_kron(const double* __restrict__ a, int ar, int ac,
+                                               const double* __restrict__ b, int br, int bc,
+                                               double* __restrict__ out) {
+    const size_t W = (size_t)ac * bc, H = (size_t)ar * br;
+    const size_t col = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= W) return;
+    const int q = (int)(col / bc), c = (int)(col % bc);
+    for (size_t row = blockIdx.y; row < H; row += gridDim.y) {
+        const int p = (int)(row / br), r = (int)(row % br);
+        out[row * W + col] = a[(size_t)p * ac + q] * b[(size_t)r * bc + c];
+    }
+}
+
+void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* b, int br, int bc, double* out) {
+    size_t W = (size_t)ac * bc, H = (size_t)ar * br;
+    int gy = (int)(H < 4096 ? H : 4096);
+    hipLaunchKernelGGL(k_kron, dim3(cdiv(W, 256), gy), dim3(256), 0, s, a, ar, ac, b, br, bc, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel #2: reductions after the factorisation: log det = 2 sum log L_rr, quad = ||L^-1 y||^2
+// (replaces torch.logdet, logpos.py:353, and the mv + dot of distributions.py:22)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_logdet_quad(const double* __restrict__ L, int ld, int n,
+                                                       const double* __restrict__ z, double* __restrict__ out_logdet,
+                                                       double* __restrict__ out_quad) {
+    __shared__ double sh[16];
+    double a = 0.0, q = 0.0;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        a += log(L[(size_t)r * ld + r]);
+        if (z) {
+            double t = z[r];
+            q += t * t;
+        }
+    }
+    a = block_sum(a, sh);
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        out_logdet[0] = 2.0 * a;
+        if (out_quad) out_quad[0] = q;
+    }
+}
+
+void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
+                      double* out_quad) {
+    hipLaunchKernelGGL(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, z, out_logdet, out_quad);
+}
+
+void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out) {
+    hipLaunchKernelGGL(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, (const double*)nullptr, out,
+                       (double*)nullptr);
+}
+
+// out[c] = sum_r R[r, c]^2 (one workgroup per column)
+__global__ __launch_bounds__(256) void k_col_sumsq(const double* __restrict__ R, int ld, int rows,
+                                                    double* __restrict__ out) {
+    __shared__ double sh[16];
+    const double* col = R + (size_t)blockIdx.x * ld;
+    double a = 0.0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) a += col[r] * col[r];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out) {
+    hipLaunchKernelGGL(k_col_sumsq, dim3(cols), dim3(256), 0, s, R, ld, rows, out);
+}
+
+// mirror the lower triangle into the upper one (column-major n x n)
+__global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld, int n) {
+    __shared__ double tile[64][65];
+    const int bi = blockIdx.x, bj = blockIdx.y;   // tile row / col, bi >= bj handled
+    if (bi < bj) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // read tile (rows bi*64.., cols bj*64..) of the lower part
+    for (int c = w; c < 64; c += 4) {
+        int r = bi * 64 + lane, cc = bj * 64 + c;
+        tile[c][lane] = (r < n && cc < n) ? A[(size_t)cc * ld + r] : 0.0;
+    }
+    __syncthreads();
+    // write transposed into (rows bj*64.., cols bi*64..)
+    for (int c = w; c < 64; c += 4) {
+        int r = bj * 64 + lane, cc = bi * 64 + c;   // element (r, cc) = lower (cc, r) = tile[lane][c]
+        if (r < n && cc < n && r < cc) A[(size_t)cc * ld + r] = tile[lane][c];
+    }
+}
+
+void fill_lower_to_full(hipStream_t s, double* A, int ld, int n) {
+    hipLaunchKernelGGL(k_sym_fill, dim3(cdiv(n, 64), cdiv(n, 64)), dim3(256), 0, s, A, ld, n);
+}
+
+// y[m N + i] = Y[i, m]  (logpos.py:338)
+__global__ void k_transpose_y(const double* __restrict__ Y, int N, int M, double* __restrict__ y) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * M) return;
+    int m = idx / N, i = idx % N;
+    y[idx] = Y[(size_t)i * M + m];
+}
+
+void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y) {
+    hipLaunchKernelGGL(k_transpose_y, dim3(cdiv((long long)N * M, 256)), dim3(256), 0, s, Y, N, M, y);
+}
+
+// prior right-hand sides: column 0 = tilde_l - mu_l, column 1+t = uL[:, t] - mu_L (logpos.py:358,363-365)
+__global__ void k_svc_prior_rhs(const double* __restrict__ pars, int N, int T, double mu_l, double mu_L,
+                                double* __restrict__ R, int ld) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    R[i] = pars[i] - mu_l;
+    for (int t = 0; t < T; ++t) R[(size_t)(1 + t) * ld + i] = pars[N + (size_t)i * T + t] - mu_L;
+}
+
+void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld) {
+    hipLaunchKernelGGL(k_svc_prior_rhs, dim3(cdiv(N, 256)), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
+}
+
+// HBM stream micro-benchmark (16 B per lane)
+__global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst,
+                                                      size_t n2) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += stride) dst[k] = src[k];
+}
+
+void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem) {
+    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, s, (const double2*)src, (double2*)dst, nelem / 2);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// kernel #5: fused adjoint of the nonseparable likelihood.
+//   G = 1/2 (alpha alpha^T - Sigma^-1),  G_ij = M x M block of the location pair (i, j)
+//   Q_ij = G_ij L_j
+//   d loglik / d L_i      = 2 sum_j K_x[i,j] tril(Q_ij)
+//   d loglik / d tilde_l_i = sum_{j != i} 2 <Q_ij, L_i> K0[i,j] (1/2 - l_i^2/A + 2 l_i^2 d_ij/A^2),  A = l_i^2 + l_j^2
+// This is what autograd re-derives through every temporary of logpos.py:339-354
+// (Nonseparable_model.py:171 NegLog.backward()).  Sinv must hold the FULL symmetric inverse.
+// One workgroup = 64 locations i x 64 locations j; lanes along i (coalesced column reads of Sinv),
+// each wave takes 16 j; the four waves' sums are combined through LDS and written as a partial row
+// part[J][i][0..T] (slot 0 = tilde_l, slots 1..T = packed tril of dL) -- no atomics, deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ x, const double* __restrict__ ell,
+                                                      const double* __restrict__ Lv,
+                                                      const double* __restrict__ alpha,
+                                                      const double* __restrict__ Sinv, int ld, int N,
+                                                      double* __restrict__ part) {
+    constexpr int T = M * (M + 1) / 2;
+    constexpr int TJ = 64;
+    __shared__ double sx[TJ], sl[TJ], sL[TJ * T], sa[TJ * M];
+    __shared__ double red[2][4][64];
+    const int I = blockIdx.x, J = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j0 = J * TJ;
+    const size_t Ns = (size_t)N;
+    if (tid < TJ) {
+        int j = j0 + tid;
+        sx[tid] = (j < N) ? x[j] : 0.0;
+        sl[tid] = (j < N) ? ell[j] : 1.0;
+    }
+    for (int k = tid; k < TJ * T; k += 256) {
+        size_t g = (size_t)j0 * T + k;
+        sL[k] = (g < Ns * T) ? Lv[g] : 0.0;
+    }
+    for (int k = tid; k < TJ * M; k += 256) {
+        int jj = k / M, m = k % M;
+        int j = j0 + jj;
+        sa[k] = (j < N) ? alpha[(size_t)m * Ns + j] : 0.0;
+    }
+    __syncthreads();
+    const int i = I * 64 + lane;
+    const bool iv = i < N;
+    const int ic = iv ? i : N - 1;
+    const double xi = x[ic], li = ell[ic];
+    const double xi2 = xi * xi, li2 = li * li;
+    double Li[T], ai[M], acc[T + 1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) Li[t] = Lv[(size_t)ic * T + t];
+#pragma unroll
+    for (int m = 0; m < M; ++m) ai[m] = alpha[(size_t)m * Ns + ic];
+#pragma unroll
+    for (int t = 0; t <= T; ++t) acc[t] = 0.0;
+    if (iv) {
+        for (int jj = 0; jj < TJ / 4; ++jj) {
+            const int k = w * (TJ / 4) + jj;
+            const int j = j0 + k;
+            if (j >= N) break;
+            const double xj = sx[k], lj = sl[k];
+            const double dist = (xi2 + xj * xj) - 2.0 * (xi * xj);
+            const double A = li2 + lj * lj;
+            const double k0 = sqrt(2.0 * (li * lj) / A) * exp(-dist / A);
+            const double kx = (i == j) ? (NMGP_JITTER + k0) : k0;
+            double G[M][M];
+#pragma unroll
+            for (int mp = 0; mp < M; ++mp) {
+                const double* col = Sinv + ((size_t)mp * Ns + j) * ld;
+#pragma unroll
+                for (int m = 0; m < M; ++m) G[m][mp] = 0.5 * (ai[m] * sa[k * M + mp] - col[(size_t)m * Ns + i]);
+            }
+            double H = 0.0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+#pragma unroll
+                for (int r = 0; r <= m; ++r) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int mp = r; mp < M; ++mp) q = fma(G[m][mp], sL[k * T + mp * (mp + 1) / 2 + r], q);
+                    acc[1 + m * (m + 1) / 2 + r] = fma(2.0 * kx, q, acc[1 + m * (m + 1) / 2 + r]);
+                    H = fma(q, Li[m * (m + 1) / 2 + r], H);
+                }
+            }
+            if (i != j) {
+                const double dlogk = 0.5 - li2 / A + 2.0 * li2 * dist / (A * A);
+                acc[0] = fma(2.0 * H * k0, dlogk, acc[0]);
+            }
+        }
+    }
+    double* o = part + ((size_t)J * Ns + ic) * (T + 1);
+#pragma unroll
+    for (int t = 0; t <= T; ++t) {
+        red[t & 1][w][lane] = acc[t];
+        __syncthreads();
+        if (w == 0 && iv) o[t] = (red[t & 1][0][lane] + red[t & 1][1][lane]) + (red[t & 1][2][lane] + red[t & 1][3][lane]);
+    }
+}
+
+int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
+                const double* Sinv, int ld, int N, int M, double* part) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+#define NMGP_ADJ(MM) hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part)
+    switch (M) {
+        case 1: NMGP_ADJ(1); break;
+        case 2: NMGP_ADJ(2); break;
+        case 3: NMGP_ADJ(3); break;
+        case 4: NMGP_ADJ(4); break;
+        case 5: NMGP_ADJ(5); break;
+        case 6: NMGP_ADJ(6); break;
+        case 7: NMGP_ADJ(7); break;
+        case 8: NMGP_ADJ(8); break;
+        default: return NMGP_E_UNSUPPORTED;
+    }
+#undef NMGP_ADJ
+    return 0;
+}
+
+// trace term: out[0] = sum_r alpha_r^2, out[1] = sum_r Sinv[r, r]
+__global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__ alpha,
+                                                       const double* __restrict__ Sinv, int ld, int n,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[16];
+    double a = 0.0, d = 0.0;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        a += alpha[r] * alpha[r];
+        d += Sinv[(size_t)r * ld + r];
+    }
+    a = block_sum(a, sh);
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = d;
+    }
+}
+
+void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out) {
+    hipLaunchKernelGGL(k_trace_terms, dim3(1), dim3(1024), 0, s, alpha, Sinv, ld, n, out);
+}
+
+// Assemble d NegLog / d pars from the adjoint partials, the prior solves and the scalar terms.
+//   R2: [N, 1+T] column-major, Sigma_prior^-1 (value - mean) per column.
+//   tr:  {sum alpha^2, trace Sinv};  hyper a, b for the inverse-gamma term (distributions.py:126-134)
+__global__ __launch_bounds__(256) void k_svc_grad_final(const double* __restrict__ part, int NJ, int N, int M, int T,
+                                                         const double* __restrict__ Lv,
+                                                         const double* __restrict__ R2, int ldR,
+                                                         const double* __restrict__ pars,
+                                                         const double* __restrict__ tr, double a, double b, int prior,
+                                                         double* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t P = (size_t)N * (1 + T) + 1;
+    if (i == 0) {
+        const double tse = pars[P - 1];
+        const double sigma2 = exp(tse);
+        double g = sigma2 * (0.5 * (tr[0] - tr[1]));
+        if (prior) g += (-a - 1.0) + b / sigma2 + 1.0;
+        grad[P - 1] = -g;
+    }
+    if (i >= N) return;
+    for (int t = 0; t <= T; ++t) {
+        double sacc = 0.0;
+        for (int J = 0; J < NJ; ++J) sacc += part[((size_t)J * N + i) * (T + 1) + t];
+        if (t == 0) {
+            if (prior) sacc -= R2[i];
+            grad[i] = -sacc;
+        } else {
+            const int tt = t - 1;
+            // diagonal slots carry the exp() reparametrisation (utils.py:16): d/d uL = d/d L * L
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= tt) ++r;
+            const bool diag = (tt == r * (r + 1) / 2 + r);
+            if (diag) sacc *= Lv[(size_t)i * T + tt];
+            if (prior) sacc -= R2[(size_t)(1 + tt) * ldR + i];
+            grad[N + (size_t)i * T + tt] = -sacc;
+        }
+    }
+}
+
+void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
+                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad) {
+    int T = M * (M + 1) / 2;
+    hipLaunchKernelGGL(k_svc_grad_final, dim3(cdiv(N, 256)), dim3(256), 0, s, part, NJ, N, M, T, Lv, R2, ldR, pars, tr,
+                       a, b, prior, grad);
+}
+
+// Scalar epilogue of the nonseparable objective (logpos.py:354-376 + distributions.py:22,126-134).
+//   sc[SC_LOGDET], sc[SC_QUAD]: likelihood reductions;  q[0..T]: prior Mahalanobis terms;
+//   hl_l / hl_L: half log-determinants of the two prior covariances.
+__global__ void k_svc_finalize(const double* __restrict__ logdet, const double* __restrict__ quad,
+                               const double* __restrict__ q, const double* __restrict__ hl_l,
+                               const double* __restrict__ hl_L, const double* __restrict__ pars, long long P, int N,
+                               int T, double a, double b, double ig_const, int prior, double* __restrict__ out5) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double LOG2PI = 1.8378770664093453;
+    const double tse = pars[P - 1];
+    const double sigma2 = exp(tse);
+    const double loglik = -0.5 * logdet[0] - 0.5 * quad[0];
+    const double lp_l = -0.5 * (N * LOG2PI + q[0]) - hl_l[0];
+    double lp_uL = 0.0;
+    for (int t = 0; t < T; ++t) lp_uL += -0.5 * (N * LOG2PI + q[1 + t]) - hl_L[0];
+    const double lp_s2 = (-a - 1.0) * log(sigma2) - b / sigma2 + ig_const;
+    double res = 0.0;
+    res += loglik;
+    if (prior) {
+        res += lp_l;
+        res += lp_uL;
+        res += lp_s2;
+        res += tse;
+    }
+    out5[0] = -res;
+    out5[1] = loglik;
+    out5[2] = lp_l;
+    out5[3] = lp_uL;
+    out5[4] = lp_s2;
+}
+
+void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
+                  const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
+                  double ig_const, int prior, double* out5) {
+    hipLaunchKernelGGL(k_svc_finalize, dim3(1), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
+                       ig_const, prior, out5);
+}
+
+// half log-determinant of a Cholesky factor: sum log L_rr
+__global__ __launch_bounds__(1024) void k_half_logdet(const double* __restrict__ L, int ld, int n,
+                                                       double* __restrict__ out) {
+    __shared__ double sh[16];
+    double a = 0.0;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) a += log(L[(size_t)r * ld + r]);
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) out[0] = a;
+}
+
+void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out) {
+    hipLaunchKernelGGL(k_half_logdet, dim3(1), dim3(1024), 0, s, L, ld, n, out);
+}
+
+}  // namespace nmgpk
