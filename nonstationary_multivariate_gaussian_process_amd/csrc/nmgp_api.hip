@@ -28,11 +28,8 @@ int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 // ---- profiling helpers ---------------------------------------------------------------------------
-struct StageScope {
-    nmgp_ctx* c;
-    int stage;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    StageScope(nmgp_ctx* ctx, int st) : c(ctx), stage(st) {
+typedef NmgpStage StageScope;
+NmgpStage::NmgpStage(nmgp_ctx* ctx, int st) : c(ctx), stage(st) {
         if (!c->profiling) return;
         StageTimer& t = c->timers[stage];
         if (!t.pool.empty()) {
@@ -44,13 +41,12 @@ struct StageScope {
             hipEventCreate(&e1);
         }
         hipEventRecord(e0, c->stream);
-    }
-    ~StageScope() {
+}
+NmgpStage::~NmgpStage() {
         if (!c->profiling || !e0) return;
         hipEventRecord(e1, c->stream);
         c->timers[stage].pending.push_back({e0, e1});
-    }
-};
+}
 
 static void profile_collect(nmgp_ctx* c) {
     for (int s = 0; s < NMGP_STAGE_COUNT; ++s) {
@@ -68,7 +64,7 @@ static void profile_collect(nmgp_ctx* c) {
 }
 
 // ---- memory helpers ---------------------------------------------------------------------------
-static int dev_alloc(nmgp_ctx* c, double** p, size_t nelem) {
+int nmgp_dev_alloc(nmgp_ctx* c, double** p, size_t nelem) {
     if (*p) {
         hipFree(*p);
         *p = nullptr;
@@ -83,10 +79,10 @@ static int dev_alloc(nmgp_ctx* c, double** p, size_t nelem) {
     return 0;
 }
 
-static int scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
+int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
     DevBuf& b = c->scratch[slot];
     if (b.cap < nelem || !b.p) {
-        NMGP_TRY(dev_alloc(c, &b.p, nelem));
+        NMGP_TRY(nmgp_dev_alloc(c, &b.p, nelem));
         b.cap = nelem;
     }
     *out = b.p;
@@ -136,7 +132,7 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
     BLAS_TRY(c, rocblas_set_stream(c->blas, c->stream));
     BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
-    NMGP_TRY(dev_alloc(c, &c->d_scal, SC_COUNT));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_scal, SC_COUNT));
     HIP_TRY(c, hipMalloc((void**)&c->d_info, 8 * sizeof(int)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, SC_COUNT * sizeof(double)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_info, 8 * sizeof(int)));
@@ -200,18 +196,18 @@ extern "C" int nmgp_set_data(nmgp_ctx* c, const double* x, const double* Y, int 
     c->P_svc = (long long)(Ns * (1 + T) + 1);
     size_t Pmax = Ns * (1 + T) + 1;
     if (2 * Ns + T + 1 > Pmax) Pmax = 2 * Ns + T + 1;
-    NMGP_TRY(dev_alloc(c, &c->d_x, Ns));
-    NMGP_TRY(dev_alloc(c, &c->d_Y, n));
-    NMGP_TRY(dev_alloc(c, &c->d_y, n));
-    NMGP_TRY(dev_alloc(c, &c->d_pars, Pmax));
-    NMGP_TRY(dev_alloc(c, &c->d_grad, Pmax));
-    NMGP_TRY(dev_alloc(c, &c->d_ell, Ns));
-    NMGP_TRY(dev_alloc(c, &c->d_sig, Ns));
-    NMGP_TRY(dev_alloc(c, &c->d_Lv, Ns * T));
-    NMGP_TRY(dev_alloc(c, &c->d_z, n));
-    NMGP_TRY(dev_alloc(c, &c->d_alpha, n));
-    NMGP_TRY(dev_alloc(c, &c->d_R, Ns * (1 + T)));
-    NMGP_TRY(dev_alloc(c, &c->d_R2, Ns * (1 + T)));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_x, Ns));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_Y, n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_y, n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_pars, Pmax));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_grad, Pmax));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_ell, Ns));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_sig, Ns));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_Lv, Ns * T));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_z, n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_alpha, n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_R, Ns * (1 + T)));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->d_R2, Ns * (1 + T)));
     HIP_TRY(c, hipMemcpyAsync(c->d_x, x, Ns * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_Y, Y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     transpose_y(c->stream, c->d_Y, N, M, c->d_y);
@@ -220,10 +216,10 @@ extern "C" int nmgp_set_data(nmgp_ctx* c, const double* x, const double* Y, int 
     return 0;
 }
 
-static int ensure_S(nmgp_ctx* c) {
+int nmgp_ensure_S(nmgp_ctx* c) {
     const size_t n = c->n;
     if (!c->d_S || c->S_cap < n * n) {
-        NMGP_TRY(dev_alloc(c, &c->d_S, n * n));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_S, n * n));
         c->S_cap = n * n;
     }
     c->ldS = c->n;
@@ -231,7 +227,7 @@ static int ensure_S(nmgp_ctx* c) {
 }
 
 // Cached Cholesky factor of RBF(x; alpha, beta) + jitter I (the GP-prior covariances of logpos.py:357,362).
-static int get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
+int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
     for (auto& p : c->priors)
         if (p.alpha == alpha && p.beta == beta) {
             *out = &p;
@@ -241,8 +237,8 @@ static int get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) 
     pf.alpha = alpha;
     pf.beta = beta;
     const size_t Ns = c->N;
-    NMGP_TRY(dev_alloc(c, &pf.L, Ns * Ns));
-    if (dev_alloc(c, &pf.logdet, 1) != 0) {
+    NMGP_TRY(nmgp_dev_alloc(c, &pf.L, Ns * Ns));
+    if (nmgp_dev_alloc(c, &pf.logdet, 1) != 0) {
         hipFree(pf.L);
         return NMGP_E_NOMEM;
     }
@@ -271,7 +267,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
     if (!hyper) return nmgp_fail(c, NMGP_E_NULL, "hyper must not be NULL");
     HIP_TRY(c, hipSetDevice(c->device));
-    NMGP_TRY(ensure_S(c));
+    NMGP_TRY(nmgp_ensure_S(c));
     const int N = c->N, M = c->M, T = c->T, n = c->n, ld = c->ldS;
     const long long P = c->P_svc;
     const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
@@ -280,15 +276,15 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     double* sc = c->d_scal;
     // priors first: the factor pointers may be created (and synchronised) here
     PriorFactor *pl = nullptr, *pL = nullptr;
-    NMGP_TRY(get_prior(c, al_l, be_l, &pl));
-    NMGP_TRY(get_prior(c, al_L, be_L, &pL));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
     // get_prior may have grown c->priors: re-resolve the first pointer
-    NMGP_TRY(get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
     if (want_grad) {
         const size_t NJ = (N + 63) / 64;
         const size_t need = NJ * (size_t)N * (T + 1);
         if (!c->d_part || c->part_cap < need) {
-            NMGP_TRY(dev_alloc(c, &c->d_part, need));
+            NMGP_TRY(nmgp_dev_alloc(c, &c->d_part, need));
             c->part_cap = need;
         }
     }
@@ -423,7 +419,7 @@ extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out)
     if (!c) return NMGP_E_NULL;
     if (!out) return nmgp_fail(c, NMGP_E_NULL, "out must not be NULL");
     NMGP_TRY(nmgp_svc_set_pars(c, pars));
-    NMGP_TRY(ensure_S(c));
+    NMGP_TRY(nmgp_ensure_S(c));
     hipStream_t s = c->stream;
     svc_prep(s, c->d_pars, c->N, c->M, c->d_ell, c->d_Lv);
     int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (c->P_svc - 1), c->d_S, c->ldS, c->N, c->M, true);
@@ -435,7 +431,7 @@ extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out)
 
 // ---- primitives --------------------------------------------------------------------------------
 static int upload(nmgp_ctx* c, int slot, const double* h, size_t nelem, double** d) {
-    NMGP_TRY(scratch_get(c, slot, nelem, d));
+    NMGP_TRY(nmgp_scratch_get(c, slot, nelem, d));
     HIP_TRY(c, hipMemcpyAsync(*d, h, nelem * sizeof(double), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
@@ -456,7 +452,7 @@ extern "C" int nmgp_pairwise_distances(nmgp_ctx* c, const double* x1, int n1, co
     double *dx1, *dx2, *dout;
     NMGP_TRY(upload(c, 0, x1, (size_t)n1 * d, &dx1));
     if (x2) NMGP_TRY(upload(c, 1, x2, (size_t)n2 * d, &dx2)); else dx2 = dx1;
-    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    NMGP_TRY(nmgp_scratch_get(c, 5, (size_t)n1 * n2, &dout));
     pairwise_rect(c->stream, dx1, n1, dx2, n2, d, dout);
     return download(c, out, dout, (size_t)n1 * n2);
 }
@@ -471,7 +467,7 @@ extern "C" int nmgp_rbf_cov(nmgp_ctx* c, const double* x1, int n1, const double*
     double *dx1, *dx2, *dout;
     NMGP_TRY(upload(c, 0, x1, (size_t)n1 * d, &dx1));
     if (x2) NMGP_TRY(upload(c, 1, x2, (size_t)n2 * d, &dx2)); else dx2 = dx1;
-    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    NMGP_TRY(nmgp_scratch_get(c, 5, (size_t)n1 * n2, &dout));
     rbf_cov_rect(c->stream, dx1, n1, dx2, n2, d, alpha, beta, x2 == nullptr, dout);
     return download(c, out, dout, (size_t)n1 * n2);
 }
@@ -486,7 +482,7 @@ extern "C" int nmgp_nonstat_rbf_cov(nmgp_ctx* c, const double* x1, const double*
     double *dx1, *dx2, *ds1 = nullptr, *dl1 = nullptr, *ds2 = nullptr, *dl2 = nullptr, *dout;
     // one upload buffer per operand: slots 0..4 hold [x1 | s1 | l1], [x2 | s2 | l2]
     double* b1;
-    NMGP_TRY(scratch_get(c, 0, (size_t)n1 * (d + 2), &b1));
+    NMGP_TRY(nmgp_scratch_get(c, 0, (size_t)n1 * (d + 2), &b1));
     dx1 = b1;
     HIP_TRY(c, hipMemcpyAsync(dx1, x1, (size_t)n1 * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (s1) {
@@ -499,7 +495,7 @@ extern "C" int nmgp_nonstat_rbf_cov(nmgp_ctx* c, const double* x1, const double*
     }
     if (x2) {
         double* b2;
-        NMGP_TRY(scratch_get(c, 1, (size_t)n2 * (d + 2), &b2));
+        NMGP_TRY(nmgp_scratch_get(c, 1, (size_t)n2 * (d + 2), &b2));
         dx2 = b2;
         HIP_TRY(c, hipMemcpyAsync(dx2, x2, (size_t)n2 * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
         if (s2) {
@@ -515,7 +511,7 @@ extern "C" int nmgp_nonstat_rbf_cov(nmgp_ctx* c, const double* x1, const double*
         ds2 = ds1;
         dl2 = dl1;
     }
-    NMGP_TRY(scratch_get(c, 5, (size_t)n1 * n2, &dout));
+    NMGP_TRY(nmgp_scratch_get(c, 5, (size_t)n1 * n2, &dout));
     gibbs_cov_rect(c->stream, dx1, ds1, dl1, n1, dx2, ds2, dl2, n2, d, x2 == nullptr, dout);
     return download(c, out, dout, (size_t)n1 * n2);
 }
@@ -530,7 +526,7 @@ extern "C" int nmgp_kron_product(nmgp_ctx* c, const double* a, int ar, int ac, c
     NMGP_TRY(upload(c, 0, a, (size_t)ar * ac, &da));
     NMGP_TRY(upload(c, 1, b, (size_t)br * bc, &db));
     const size_t tot = (size_t)ar * ac * br * bc;
-    NMGP_TRY(scratch_get(c, 5, tot, &dout));
+    NMGP_TRY(nmgp_scratch_get(c, 5, tot, &dout));
     kron_product(c->stream, da, ar, ac, db, br, bc, dout);
     return download(c, out, dout, tot);
 }
@@ -573,8 +569,8 @@ extern "C" int nmgp_measure_hbm_gbs(nmgp_ctx* c, long long bytes, int reps, doub
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nelem = ((size_t)bytes / 16) * 2;
     double *src, *dst;
-    NMGP_TRY(scratch_get(c, 3, nelem, &src));
-    NMGP_TRY(scratch_get(c, 4, nelem, &dst));
+    NMGP_TRY(nmgp_scratch_get(c, 3, nelem, &src));
+    NMGP_TRY(nmgp_scratch_get(c, 4, nelem, &dst));
     HIP_TRY(c, hipMemsetAsync(src, 0, nelem * sizeof(double), c->stream));
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
@@ -599,9 +595,9 @@ extern "C" int nmgp_measure_dgemm_tflops(nmgp_ctx* c, int n, int reps, double* t
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nn = (size_t)n * n;
     double *A, *B, *C;
-    NMGP_TRY(scratch_get(c, 2, nn, &A));
-    NMGP_TRY(scratch_get(c, 3, nn, &B));
-    NMGP_TRY(scratch_get(c, 4, nn, &C));
+    NMGP_TRY(nmgp_scratch_get(c, 2, nn, &A));
+    NMGP_TRY(nmgp_scratch_get(c, 3, nn, &B));
+    NMGP_TRY(nmgp_scratch_get(c, 4, nn, &C));
     // pseudo-random, non-trivial operands (zero-filled operands over-state the sustainable clock)
     std::vector<double> h(nn);
     unsigned long long st = 88172645463325252ull;

@@ -1,51 +1,785 @@
-// Separable / stationary objectives, Kronecker-structured primitives and deterministic prediction.
-// (entry points declared in include/nmgp.h)
+// Separable / stationary objectives (logpos.py:216-296, 383-462), Kronecker-structured primitives
+// (kronecker_operation.py:36-85, distributions.py:10-113) and deterministic prediction
+// (prediction.py:337-458, 912-1036, 1566-1638).  Entry points declared in include/nmgp.h.
+//
+// The N x N eigendecomposition is rocSOLVER dsyevd; the M x M one (M <= 8 for the objectives) is a cyclic Jacobi
+// on the host: a 5 x 5 matrix is not GPU work.  Everything that scales with N or N^2 runs in hand-written kernels
+// (nmgp_kernels_eig.hip) or rocBLAS GEMM/TRSM.
+#include <algorithm>
+
 #include "nmgp_internal.h"
 
 using namespace nmgpk;
 
-#define NMGP_TODO(ctx, name) return nmgp_fail(ctx, NMGP_E_UNSUPPORTED, name " is not implemented yet")
+namespace {
 
-extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double*, const double[9], int, double[6], double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_logpos_sep");
+const double LOG2PI = 1.8378770664093453;
+
+// scratch slot assignment of this translation unit (slots 0..5 belong to nmgp_api.hip)
+enum { SL_A = 6, SL_SMALL = 7, SL_K3 = 8, SL_U = 9, SL_PART = 10, SL_G = 11, SL_X = 12, SL_Y = 13, SL_BIG = 14, SL_BIG2 = 15 };
+
+// ---- small dense helpers on the host ----------------------------------------------------------------
+// cyclic Jacobi eigendecomposition of the symmetric matrix whose UPPER triangle is given (row-major A, like
+// torch.symeig's default).  w ascending, V[m*M + p] = component m of eigenvector p.
+void jacobi_eigh(int M, const double* Ain, std::vector<double>& w, std::vector<double>& V) {
+    std::vector<double> A((size_t)M * M);
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) A[(size_t)i * M + j] = (i <= j) ? Ain[(size_t)i * M + j] : Ain[(size_t)j * M + i];
+    V.assign((size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i) V[(size_t)i * M + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j) (i == j ? diag : off) += A[(size_t)i * M + j] * A[(size_t)i * M + j];
+        if (off <= 1e-34 * (diag + 1e-300)) break;
+        for (int p = 0; p < M - 1; ++p)
+            for (int q = p + 1; q < M; ++q) {
+                const double apq = A[(size_t)p * M + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * M + p], aqq = A[(size_t)q * M + q];
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+                const double cth = 1.0 / std::sqrt(1.0 + t * t), sth = t * cth;
+                for (int k = 0; k < M; ++k) {
+                    const double akp = A[(size_t)k * M + p], akq = A[(size_t)k * M + q];
+                    A[(size_t)k * M + p] = cth * akp - sth * akq;
+                    A[(size_t)k * M + q] = sth * akp + cth * akq;
+                }
+                for (int k = 0; k < M; ++k) {
+                    const double apk = A[(size_t)p * M + k], aqk = A[(size_t)q * M + k];
+                    A[(size_t)p * M + k] = cth * apk - sth * aqk;
+                    A[(size_t)q * M + k] = sth * apk + cth * aqk;
+                }
+                for (int k = 0; k < M; ++k) {
+                    const double vkp = V[(size_t)k * M + p], vkq = V[(size_t)k * M + q];
+                    V[(size_t)k * M + p] = cth * vkp - sth * vkq;
+                    V[(size_t)k * M + q] = sth * vkp + cth * vkq;
+                }
+            }
+    }
+    std::vector<int> idx(M);
+    for (int i = 0; i < M; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return A[(size_t)a * M + a] < A[(size_t)b * M + b]; });
+    w.resize(M);
+    std::vector<double> Vs((size_t)M * M);
+    for (int p = 0; p < M; ++p) {
+        w[p] = A[(size_t)idx[p] * M + idx[p]];
+        for (int m = 0; m < M; ++m) Vs[(size_t)m * M + p] = V[(size_t)m * M + idx[p]];
+    }
+    V.swap(Vs);
 }
-extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double*, const double[5], int, double[5], double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_logpos_sta");
+
+// packed tril (exp on the diagonal slots when `unconstrained`) -> dense L (row-major M x M) and B = L L^T
+void build_B(const double* uL, int M, bool unconstrained, std::vector<double>& L, std::vector<double>& B) {
+    L.assign((size_t)M * M, 0.0);
+    int t = 0;
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c <= r; ++c, ++t) L[(size_t)r * M + c] = (c == r && unconstrained) ? std::exp(uL[t]) : uL[t];
+    B.assign((size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < M; ++k) s += L[(size_t)i * M + k] * L[(size_t)j * M + k];
+            B[(size_t)i * M + j] = s;
+        }
 }
-extern "C" int nmgp_kron_mv(nmgp_ctx* c, const double*, int, int, const double*, int, int, const double*, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_kron_mv");
+
+// float32-rounded Normal(mean, sd).log_prob as torch evaluates it when mean/sd are Python numbers
+// (logpos.py:283,446,450; see oracle.normal_log_prob).  Returns log prob and d/dv.
+double normal_logprob_f32(double v, double mean, double sd, double* dv) {
+    const float m32 = (float)mean, s32 = (float)sd;
+    const double var = (double)(s32 * s32);
+    const double log_sd = (double)std::log(s32);
+    const double r = v - (double)m32;
+    if (dv) *dv = -r / var;
+    return -(r * r) / (2.0 * var) - log_sd - std::log(std::sqrt(2.0 * M_PI));
 }
-extern "C" int nmgp_mvn_logpdf_kron(nmgp_ctx* c, const double*, const double*, const double*, int, const double*, int,
-                                    double, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_mvn_logpdf_kron");
+
+struct EigWork {
+    int N = 0, M = 0;
+    double* V = nullptr;    // [N, N] eigenvectors (column-major)
+    double* wK = nullptr;   // [N]
+    double* a = nullptr;    // [M N] projection of y (then alpha in the eigenbasis)
+    double* wB = nullptr;   // [M]      device
+    double* VB = nullptr;   // [M, M]   device, row-major
+    double* VBt = nullptr;  // [M, M]   device, row-major transpose
+    double* sums = nullptr; // [8]
+    double* sig2 = nullptr; // device scalar
+    std::vector<double> h_wB, h_VB, h_L, h_B;
+};
+
+int ensure_eig_buffers(nmgp_ctx* c, int N) {
+    const size_t nn = (size_t)N * N;
+    if (!c->d_K || c->K_cap < nn) {
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_K, nn));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_K2, nn));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_w, (size_t)N));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_E, (size_t)N));
+        c->K_cap = nn;
+    }
+    return 0;
 }
-extern "C" int nmgp_mvn_logpdf_dense(nmgp_ctx* c, const double*, const double*, const double*, int, const double*, int,
-                                     double, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_mvn_logpdf_dense");
+
+// Eigendecompose the symmetric N x N matrix whose lower triangle (column-major) is in c->d_K.
+int eig_K(nmgp_ctx* c, int N) {
+    NmgpStage sp(c, NMGP_STAGE_EIG);
+    HIP_TRY(c, hipMemsetAsync(c->d_info + 3, 0, sizeof(int), c->stream));
+    BLAS_TRY(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_lower, N, c->d_K, N, c->d_w, c->d_E,
+                                 c->d_info + 3));
+    return 0;
 }
-extern "C" int nmgp_kron_inv_logdet(nmgp_ctx* c, double, const double*, int, const double*, int, double*, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_kron_inv_logdet");
+
+int check_eig_info(nmgp_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_info + 3, c->d_info + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_info[3] != 0)
+        return nmgp_fail(c, NMGP_NUM_EIG, "symmetric eigensolver did not converge (info=%d)", c->h_info[3]);
+    return 0;
 }
-extern "C" int nmgp_predict_svc(nmgp_ctx* c, const double*, const double[8], const double*, int, double*, double*,
-                                double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_predict_svc");
+
+// Upload the small host-side eigendecomposition of B into device scratch; sets the EigWork pointers.
+int setup_small(nmgp_ctx* c, EigWork& w, int M, int N, double sigma2) {
+    w.M = M;
+    w.N = N;
+    double* sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_SMALL, (size_t)3 * M * M + M + 32, &sm));
+    w.wB = sm;
+    w.VB = sm + M;
+    w.VBt = w.VB + (size_t)M * M;
+    w.sums = w.VBt + (size_t)M * M;
+    w.sig2 = w.sums + 16;
+    std::vector<double> h((size_t)2 * M * M + M);
+    for (int p = 0; p < M; ++p) h[p] = w.h_wB[p];
+    for (int m = 0; m < M; ++m)
+        for (int p = 0; p < M; ++p) {
+            h[M + (size_t)m * M + p] = w.h_VB[(size_t)m * M + p];
+            h[M + (size_t)M * M + (size_t)p * M + m] = w.h_VB[(size_t)m * M + p];
+        }
+    HIP_TRY(c, hipMemcpyAsync(sm, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(w.sig2, &sigma2, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));    // h and sigma2 are stack/heap temporaries
+    NMGP_TRY(nmgp_scratch_get(c, SL_A, (size_t)M * N, &w.a));
+    w.V = c->d_K;
+    w.wK = c->d_w;
+    return 0;
 }
-extern "C" int nmgp_predict_sep(nmgp_ctx* c, const double*, const double[9], const double*, int, double*, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_predict_sep");
+
+// loglik of N(0, B kron K + sigma2 I) at the vector d_yv (output-major, device), K's lower triangle in c->d_K.
+// On return: V in d_K, wK, a (scaled by w if want_scaled), sums[0..3] on the host in hs.
+int kron_loglik(nmgp_ctx* c, EigWork& w, const double* d_yv, double sigma2, bool want_scaled, double hs[4],
+                double* loglik) {
+    const int N = w.N, M = w.M;
+    NMGP_TRY(eig_K(c, N));
+    {
+        NmgpStage sp(c, NMGP_STAGE_KRONMV);
+        int r = kron_mv(c->stream, w.V, N, N, d_yv, w.VBt, M, M, w.a);   // a = (V_B^T kron V_K^T) y  (distributions.py:43)
+        if (r) return nmgp_fail(c, r, "kron_mv: more than 64 outputs are not supported");
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_REDUCE);
+        eig_reduce(c->stream, w.a, w.wB, M, w.wK, N, w.sig2, want_scaled, w.sums);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_pin + 64, w.sums, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NMGP_TRY(check_eig_info(c));
+    for (int k = 0; k < 4; ++k) hs[k] = c->h_pin[64 + k];
+    *loglik = -0.5 * hs[0] - 0.5 * hs[1];                                   // distributions.py:51
+    return 0;
 }
-extern "C" int nmgp_predict_sta(nmgp_ctx* c, const double*, const double*, int, double*, double*) {
-    if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_predict_sta");
+
+// Adjoint of the Kronecker likelihood: per-location gradients (d_g: [2N] = g_tl | g_ts on the device),
+// dB (host, M x M) and d loglik / d sigma2.  Requires kron_loglik(want_scaled=true) to have run.
+int kron_adjoint(nmgp_ctx* c, EigWork& w, const double* d_ell, const double* d_sig, const double hs[4], double* d_g,
+                 std::vector<double>& dB, double* dsigma2) {
+    const int N = w.N, M = w.M;
+    hipStream_t s = c->stream;
+    const double one = 1.0, zero = 0.0;
+    double *C, *U, *part, *coreB;
+    NMGP_TRY(nmgp_scratch_get(c, SL_K3, (size_t)N * N, &C));
+    NMGP_TRY(nmgp_scratch_get(c, SL_U, (size_t)N * M + (size_t)M * M, &U));
+    coreB = U + (size_t)N * M;
+    const int NJ = (N + 63) / 64;
+    NMGP_TRY(nmgp_scratch_get(c, SL_PART, (size_t)NJ * N * 2, &part));
+    {
+        NmgpStage sp(c, NMGP_STAGE_INVERSE);
+        // C = V diag(dvec) V^T, dvec[q] = sum_p wB[p] w[p,q]
+        colscale_d(s, w.V, w.wB, M, w.wK, N, w.sig2, c->d_K2);
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, c->d_K2, N,
+                                  w.V, N, &zero, C, N));
+        // U = V At^T  (At = alpha in the eigenbasis, [M, N] row-major == [N, M] column-major)
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, N, M, N, &one, w.V, N, w.a, N,
+                                  &zero, U, N));
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_ADJOINT);
+        sep_adjoint(s, c->d_x, d_ell, d_sig, U, w.wB, M, C, N, part);
+        sep_grad_sum(s, part, NJ, N, d_g);
+        sep_coreB(s, w.a, w.wB, M, w.wK, N, w.sig2, coreB);
+    }
+    std::vector<double> hc((size_t)M * M);
+    HIP_TRY(c, hipMemcpyAsync(hc.data(), coreB, hc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    // dB = 1/2 V_B coreB V_B^T
+    dB.assign((size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) {
+            double acc = 0.0;
+            for (int p = 0; p < M; ++p)
+                for (int q = 0; q < M; ++q) acc += w.h_VB[(size_t)i * M + p] * hc[(size_t)p * M + q] * w.h_VB[(size_t)j * M + q];
+            dB[(size_t)i * M + j] = 0.5 * acc;
+        }
+    *dsigma2 = 0.5 * (hs[2] - hs[3]);
+    return 0;
 }
-extern "C" int nmgp_mvn_logpdf(nmgp_ctx* c, const double*, const double*, double, const double*, int, double*) {
+
+// chain dB -> gradient w.r.t. the unconstrained packed factor (exp on the diagonal slots)
+void dB_to_guL(const std::vector<double>& dB, const std::vector<double>& L, int M, std::vector<double>& g) {
+    g.assign((size_t)M * (M + 1) / 2, 0.0);
+    int t = 0;
+    for (int r = 0; r < M; ++r)
+        for (int cc = 0; cc <= r; ++cc, ++t) {
+            double acc = 0.0;
+            for (int k = 0; k < M; ++k) acc += (dB[(size_t)r * M + k] + dB[(size_t)k * M + r]) * L[(size_t)k * M + cc];
+            g[t] = (cc == r) ? acc * L[(size_t)r * M + r] : acc;
+        }
+}
+
+// log N(v; mu 1, RBF(x; alpha, beta) + jitter I) for the columns of R (already v - mu), via the cached factor.
+// q_out[k] = Mahalanobis term of column k; if R2 != null also Sigma^-1 r (for the gradient).
+int prior_solve(nmgp_ctx* c, PriorFactor* pf, double* R, int ncol, double* R2) {
+    const double one = 1.0;
+    const int N = c->N;
+    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+    if (R2) {
+        HIP_TRY(c, hipMemcpyAsync(R2, R, (size_t)N * ncol * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                  rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R2, N));
+    }
+    return 0;
+}
+
+int require_data(nmgp_ctx* c) {
+    if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// separable objective
+// =================================================================================================
+extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyper[9], int prior, double out6[6],
+                               double* grad) {
     if (!c) return NMGP_E_NULL;
-    NMGP_TODO(c, "nmgp_mvn_logpdf");
+    if (!pars || !hyper || !out6) return nmgp_fail(c, NMGP_E_NULL, "pars/hyper/out6 must not be NULL");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T;
+    const size_t P = (size_t)2 * N + T + 1;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_s = hyper[3], al_s = hyper[4], be_s = hyper[5];
+    const double a = hyper[6], b = hyper[7], cc = hyper[8];
+    hipStream_t s = c->stream;
+    const double tse = pars[P - 1];
+    const double sigma2 = std::exp(tse);
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    HIP_TRY(c, hipMemcpyAsync(c->d_pars, pars, P * sizeof(double), hipMemcpyHostToDevice, s));
+    EigWork w;
+    build_B(pars + 2 * N, M, true, w.h_L, w.h_B);
+    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        exp_vec(s, c->d_pars, N, c->d_ell);
+        exp_vec(s, c->d_pars + N, N, c->d_sig);
+        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
+    }
+    double hs[4], loglik;
+    NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    // GP priors on tilde_l and tilde_sigma (logpos.py:271-281)
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    double q[2], hl[2];
+    {
+        NmgpStage sp(c, NMGP_STAGE_PRIOR);
+        two_col_rhs(s, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
+        double* R2 = (grad && prior) ? c->d_R2 : nullptr;
+        if (pl == ps) {
+            NMGP_TRY(prior_solve(c, pl, c->d_R, 2, R2));
+        } else {
+            NMGP_TRY(prior_solve(c, pl, c->d_R, 1, R2));
+            NMGP_TRY(prior_solve(c, ps, c->d_R + N, 1, R2 ? R2 + N : nullptr));
+        }
+        col_sumsq(s, c->d_R, N, N, 2, w.sums + 8);
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 72, w.sums + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 74, pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 75, ps->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        q[0] = c->h_pin[72]; q[1] = c->h_pin[73]; hl[0] = c->h_pin[74]; hl[1] = c->h_pin[75];
+    }
+    const double lp_l = -0.5 * (N * LOG2PI + q[0]) - hl[0];
+    const double lp_s = -0.5 * (N * LOG2PI + q[1]) - hl[1];
+    double lp_uL = 0.0;
+    std::vector<double> g_uL_prior(T, 0.0);
+    for (int t = 0; t < T; ++t) lp_uL += normal_logprob_f32(pars[2 * N + t], 0.0, cc, &g_uL_prior[t]);   // logpos.py:283
+    const double lp_s2 = (-a - 1.0) * std::log(sigma2) - b / sigma2 + a * std::log(b) - std::lgamma(a);
+    double res = 0.0;
+    res += loglik;
+    if (prior) { res += lp_l; res += lp_s; res += lp_uL; res += lp_s2; res += tse; }
+    out6[0] = -res; out6[1] = loglik; out6[2] = lp_l; out6[3] = lp_s; out6[4] = lp_uL; out6[5] = lp_s2;
+    if (grad) {
+        double* d_g;
+        NMGP_TRY(nmgp_scratch_get(c, SL_G, (size_t)2 * N, &d_g));
+        std::vector<double> dB, g_uL;
+        double ds;
+        NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
+        dB_to_guL(dB, w.h_L, M, g_uL);
+        std::vector<double> hg((size_t)2 * N), hr((size_t)2 * N, 0.0);
+        HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (prior) HIP_TRY(c, hipMemcpyAsync(hr.data(), c->d_R2, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int i = 0; i < 2 * N; ++i) grad[i] = -(hg[i] - hr[i]);
+        for (int t = 0; t < T; ++t) grad[2 * N + t] = -(g_uL[t] + (prior ? g_uL_prior[t] : 0.0));
+        double ge = sigma2 * ds;
+        if (prior) ge += (-a - 1.0) + b / sigma2 + 1.0;
+        grad[P - 1] = -ge;
+    }
+    if (!std::isfinite(out6[1])) return nmgp_fail(c, NMGP_NUM_NAN, "non-finite separable likelihood (%g)", out6[1]);
+    return 0;
+}
+
+// =================================================================================================
+// stationary objective
+// =================================================================================================
+extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyper[5], int prior, double out5[5],
+                               double* grad) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars || !hyper || !out5) return nmgp_fail(c, NMGP_E_NULL, "pars/hyper/out5 must not be NULL");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T;
+    const size_t P = (size_t)T + 3;
+    const double mu_l = hyper[0], sd_l = hyper[1], a = hyper[2], b = hyper[3], cc = hyper[4];
+    hipStream_t s = c->stream;
+    const double tl = pars[0], ts = pars[1], tse = pars[P - 1];
+    const double sigma2 = std::exp(tse);
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    EigWork w;
+    build_B(pars + 2, M, true, w.h_L, w.h_B);
+    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        // l = exp(tilde_l * ones(N)), sigma = exp(tilde_sigma * ones(N))  (logpos.py:424-425)
+        fill_vec(s, c->d_R, N, tl);
+        fill_vec(s, c->d_R + N, N, ts);
+        exp_vec(s, c->d_R, N, c->d_ell);
+        exp_vec(s, c->d_R + N, N, c->d_sig);
+        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:429
+    }
+    double hs[4], loglik;
+    NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    double dl = 0.0, lp_l = 0.0, lp_uL = 0.0, lp_s2 = 0.0;
+    std::vector<double> g_uL_prior(T, 0.0);
+    // the reference only evaluates the prior terms when Prior is true (logpos.py:445-458)
+    lp_l = normal_logprob_f32(tl, mu_l, sd_l, &dl);
+    for (int t = 0; t < T; ++t) lp_uL += normal_logprob_f32(pars[2 + t], 0.0, cc, &g_uL_prior[t]);
+    lp_s2 = (-a - 1.0) * std::log(sigma2) - b / sigma2 + a * std::log(b) - std::lgamma(a);
+    double res = 0.0;
+    res += loglik;
+    if (prior) { res += lp_l; res += lp_uL; res += lp_s2; res += tse; }
+    out5[0] = -res; out5[1] = loglik; out5[2] = lp_l; out5[3] = lp_uL; out5[4] = lp_s2;
+    if (grad) {
+        double* d_g;
+        NMGP_TRY(nmgp_scratch_get(c, SL_G, (size_t)2 * N + 8, &d_g));
+        std::vector<double> dB, g_uL;
+        double ds;
+        NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
+        dB_to_guL(dB, w.h_L, M, g_uL);
+        std::vector<double> hg((size_t)2 * N);
+        HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        double gtl = 0.0, gts = 0.0;       // the scalar curves move every location together
+        for (int i = 0; i < N; ++i) { gtl += hg[i]; gts += hg[N + i]; }
+        if (prior) gtl += dl;
+        grad[0] = -gtl;
+        grad[1] = -gts;
+        for (int t = 0; t < T; ++t) grad[2 + t] = -(g_uL[t] + (prior ? g_uL_prior[t] : 0.0));
+        double ge = sigma2 * ds;
+        if (prior) ge += (-a - 1.0) + b / sigma2 + 1.0;
+        grad[P - 1] = -ge;
+    }
+    if (!std::isfinite(out5[1])) return nmgp_fail(c, NMGP_NUM_NAN, "non-finite stationary likelihood (%g)", out5[1]);
+    return 0;
+}
+
+// =================================================================================================
+// Kronecker primitives
+// =================================================================================================
+extern "C" int nmgp_kron_mv(nmgp_ctx* c, const double* B, int m1, int m2, const double* K, int n1, int n2,
+                            const double* y, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!B || !K || !y || !out) return nmgp_fail(c, NMGP_E_NULL, "B/K/y/out must not be NULL");
+    if (m1 <= 0 || m2 <= 0 || n1 <= 0 || n2 <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    double *dK, *dy, *dB, *dout;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)n1 * n2, &dK));
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)m2 * n2 + (size_t)m1 * m2 + (size_t)m1 * n1, &dy));
+    dB = dy + (size_t)m2 * n2;
+    dout = dB + (size_t)m1 * m2;
+    HIP_TRY(c, hipMemcpyAsync(dK, K, (size_t)n1 * n2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(dy, y, (size_t)m2 * n2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(dB, B, (size_t)m1 * m2 * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+        NmgpStage sp(c, NMGP_STAGE_KRONMV);
+        int r = kron_mv(s, dK, n1, n2, dy, dB, m1, m2, dout);
+        if (r) return nmgp_fail(c, r, "kron_mv supports at most 64 columns in B (got %d)", m2);
+    }
+    HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)m1 * n1 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int nmgp_mvn_logpdf(nmgp_ctx* c, const double* y, const double* mu, double logdet, const double* inv, int n,
+                               double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!y || !inv || !out) return nmgp_fail(c, NMGP_E_NULL, "y/invSigma/out must not be NULL");
+    if (n <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "n must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    double *dI, *dv;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)n * n, &dI));
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)4 * n + 8, &dv));
+    double *dy = dv, *dmu = dv + n, *dr = dv + 2 * n, *dt = dv + 3 * n, *dres = dv + 4 * n;
+    HIP_TRY(c, hipMemcpyAsync(dI, inv, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (mu) HIP_TRY(c, hipMemcpyAsync(dmu, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    sub_vec(s, dy, mu ? dmu : nullptr, n, dr);
+    const double one = 1.0, zero = 0.0;
+    // row-major invSigma times r == (column-major view)^T r   (torch.mv, distributions.py:22)
+    BLAS_TRY(c, rocblas_dgemv(c->blas, rocblas_operation_transpose, n, n, &one, dI, n, dr, 1, &zero, dt, 1));
+    dot(s, dr, dt, n, dres);
+    double h = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(&h, dres, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *out = -0.5 * logdet - 0.5 * h;
+    return 0;
+}
+
+// shared front end of the Kronecker-density primitives: uploads K (lower triangle of the column-major view ==
+// upper triangle of the row-major matrix, torch.symeig's default) and y - mu.
+static int kron_density_setup(nmgp_ctx* c, const double* y, const double* mu, const double* K, int M, int N, double** dr) {
+    hipStream_t s = c->stream;
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    const size_t n = (size_t)M * N;
+    double* dv;
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, 3 * n, &dv));
+    HIP_TRY(c, hipMemcpyAsync(c->d_K, K, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(dv, y, n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (mu) HIP_TRY(c, hipMemcpyAsync(dv + n, mu, n * sizeof(double), hipMemcpyHostToDevice, s));
+    sub_vec(s, dv, mu ? dv + n : nullptr, (int)n, dv + 2 * n);
+    *dr = dv + 2 * n;
+    return 0;
+}
+
+extern "C" int nmgp_mvn_logpdf_kron(nmgp_ctx* c, const double* y, const double* mu, const double* B, int M,
+                                    const double* K, int N, double sigma2, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!y || !B || !K || !out) return nmgp_fail(c, NMGP_E_NULL, "y/B/K/out must not be NULL");
+    if (M <= 0 || N <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape M=%d N=%d", M, N);
+    if (M > 64) return nmgp_fail(c, NMGP_E_UNSUPPORTED, "M=%d > 64 outputs", M);
+    HIP_TRY(c, hipSetDevice(c->device));
+    double* dr;
+    NMGP_TRY(kron_density_setup(c, y, mu, K, M, N, &dr));
+    EigWork w;
+    jacobi_eigh(M, B, w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    double hs[4], loglik;
+    int r = kron_loglik(c, w, dr, sigma2, false, hs, &loglik);
+    *out = loglik;
+    if (r) return r;
+    if (!std::isfinite(loglik)) return nmgp_fail(c, NMGP_NUM_NAN, "non-finite log density");
+    return 0;
+}
+
+// Builds S = kron(B, K) + sigma2 I (row-major == column-major, symmetric inputs assumed) in scratch SL_BIG2.
+static int dense_kron_cov(nmgp_ctx* c, const double* B, int M, const double* K, int N, double sigma2, double** dS) {
+    hipStream_t s = c->stream;
+    const size_t n = (size_t)M * N;
+    double *dB, *dK;
+    NMGP_TRY(nmgp_scratch_get(c, SL_X, (size_t)M * M, &dB));
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)N * N, &dK));
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, n * n, dS));
+    HIP_TRY(c, hipMemcpyAsync(dB, B, (size_t)M * M * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(dK, K, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+    kron_product(s, dB, M, M, dK, N, N, *dS);
+    add_diag(s, *dS, (int)n, (int)n, sigma2);
+    return 0;
+}
+
+extern "C" int nmgp_mvn_logpdf_dense(nmgp_ctx* c, const double* y, const double* mu, const double* B, int M,
+                                     const double* K, int N, double sigma2, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!y || !B || !K || !out) return nmgp_fail(c, NMGP_E_NULL, "y/B/K/out must not be NULL");
+    if (M <= 0 || N <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape M=%d N=%d", M, N);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = M * N;
+    double *dS, *dv;
+    NMGP_TRY(dense_kron_cov(c, B, M, K, N, sigma2, &dS));
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)3 * n + 8, &dv));
+    HIP_TRY(c, hipMemcpyAsync(dv, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (mu) HIP_TRY(c, hipMemcpyAsync(dv + n, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    double* dr = dv + 2 * (size_t)n;
+    sub_vec(s, dv, mu ? dv + n : nullptr, n, dr);
+    HIP_TRY(c, hipMemsetAsync(c->d_info + 4, 0, sizeof(int), s));
+    BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, dS, n, c->d_info + 4));
+    BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n, dS, n,
+                              dr, 1));
+    double* dres = dv + 3 * (size_t)n;
+    chol_logdet_quad(s, dS, n, n, dr, dres, dres + 1);
+    double h[2];
+    HIP_TRY(c, hipMemcpyAsync(h, dres, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_info + 4, c->d_info + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_info[4] != 0)
+        return nmgp_fail(c, c->h_info[4], "B kron K + sigma2 I is not positive definite (leading minor %d)", c->h_info[4]);
+    *out = -0.5 * h[0] - 0.5 * h[1];
+    return 0;
+}
+
+extern "C" int nmgp_kron_inv_logdet(nmgp_ctx* c, double sigma2, const double* B, int M, const double* K, int N,
+                                    double* out_inv, double* out_logdet) {
+    if (!c) return NMGP_E_NULL;
+    if (!B || !K) return nmgp_fail(c, NMGP_E_NULL, "B/K must not be NULL");
+    if (M <= 0 || N <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bad shape M=%d N=%d", M, N);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t n = (size_t)M * N;
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    HIP_TRY(c, hipMemcpyAsync(c->d_K, K, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+    EigWork w;
+    jacobi_eigh(M, B, w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    NMGP_TRY(eig_K(c, N));
+    NMGP_TRY(check_eig_info(c));
+    double* dw;
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, n + 8, &dw));
+    kron_w(s, w.wB, M, w.wK, N, sigma2, dw);                      // 1 / (t + sigma2), kronecker_operation.py:52
+    if (out_logdet) {
+        // sum log(t + sigma2) = - sum log w   (kronecker_operation.py:69)
+        std::vector<double> hw(n);
+        HIP_TRY(c, hipMemcpyAsync(hw.data(), dw, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        std::vector<double> hk(N);
+        HIP_TRY(c, hipMemcpyAsync(hk.data(), w.wK, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        double acc = 0.0;
+        for (int p = 0; p < M; ++p)
+            for (int q = 0; q < N; ++q) acc += std::log(w.h_wB[p] * hk[q] + sigma2);
+        *out_logdet = acc;
+    }
+    if (out_inv) {
+        double *U, *Us, *C;
+        NMGP_TRY(nmgp_scratch_get(c, SL_BIG, n * n, &U));
+        NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, n * n, &Us));
+        NMGP_TRY(nmgp_scratch_get(c, SL_K3, n * n, &C));
+        kron_eigvec(s, w.VB, M, w.V, N, U);                       // U = V_B kron V_K, row-major (kronecker_operation.py:50)
+        // row-major U with columns scaled by w: Us_rm[r, k] = U_rm[r, k] w[k]  ==  column-major rows scaled.
+        // C = U_rm diag(w) U_rm^T = (U_cm^T) diag(w) (U_cm): scale the ROWS of the column-major view.
+        // rocBLAS has no row-scaling; use dgemm on the transposes: build D = diag(w) implicitly through dgmm.
+        BLAS_TRY(c, rocblas_ddgmm(c->blas, rocblas_side_left, (int)n, (int)n, U, (int)n, dw, 1, Us, (int)n));
+        const double one = 1.0, zero = 0.0;
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, (int)n, (int)n, (int)n,
+                                  &one, U, (int)n, Us, (int)n, &zero, C, (int)n));
+        HIP_TRY(c, hipMemcpyAsync(out_inv, C, n * n * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+// =================================================================================================
+// deterministic prediction
+// =================================================================================================
+// GP-regression of the latent curves at new inputs (prediction.py:926-941): proj[s, k] = k*(xs_s)^T Sigma^-1 r_k
+// with r_k the k-th column of R (already value - mean).  Kstar is built as RBF(xs, x) row-major [S, N] ==
+// column-major [N, S].  proj: column-major [S, ncol].
+static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, double* R /*[N,ncol] -> solved*/,
+                      int ncol, double* proj) {
+    const int N = c->N;
+    hipStream_t s = c->stream;
+    const double one = 1.0, zero = 0.0;
+    double* Ks;
+    NMGP_TRY(nmgp_scratch_get(c, SL_X, (size_t)N * S, &Ks));
+    rbf_cov_rect(s, d_xs, S, c->d_x, N, 1, pf->alpha, pf->beta, false, Ks);
+    // w = Sigma^-1 r through the cached Cholesky factor
+    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, S, ncol, N, &one, Ks, N, R,
+                              N, &zero, proj, S));
+    return 0;
+}
+
+extern "C" int nmgp_predict_svc(nmgp_ctx* c, const double* pars, const double hyper[8], const double* xs, int S,
+                                double* mean, double* var, double* Lstar) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars || !hyper || !xs || !mean || !var) return nmgp_fail(c, NMGP_E_NULL, "null argument");
+    if (S <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "S must be positive");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T, n = c->n;
+    const long long P = c->P_svc;
+    hipStream_t s = c->stream;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
+    NMGP_TRY(nmgp_ensure_S(c));
+    const int ld = c->ldS;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pars, pars, (size_t)P * sizeof(double), hipMemcpyHostToDevice, s));
+    PriorFactor *pl = nullptr, *pL = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    double* sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)S * (2 + 2 * T + 3 * M) + 16, &sm));
+    double* d_xs = sm;
+    double* proj = d_xs + S;                      // [S, 1+T]
+    double* tl_star = proj + (size_t)S * (1 + T);
+    double* Ls = tl_star + S;                     // [S, T]
+    double* d_mean = Ls + (size_t)S * T;          // [S*M]
+    double* d_colsq = d_mean + (size_t)S * M;
+    double* d_var = d_colsq + (size_t)S * M;
+    HIP_TRY(c, hipMemcpyAsync(d_xs, xs, (size_t)S * sizeof(double), hipMemcpyHostToDevice, s));
+    svc_prior_rhs(s, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
+    if (pl == pL) {
+        NMGP_TRY(gp_project(c, pl, d_xs, S, c->d_R, 1 + T, proj));
+    } else {
+        NMGP_TRY(gp_project(c, pl, d_xs, S, c->d_R, 1, proj));
+        NMGP_TRY(gp_project(c, pL, d_xs, S, c->d_R + N, T, proj + S));
+    }
+    svc_star(s, proj, S, M, mu_l, mu_L, tl_star, Ls);
+    // Sigma, its factor, alpha = Sigma^-1 y
+    svc_prep(s, c->d_pars, N, M, c->d_ell, c->d_Lv);
+    int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (P - 1), c->d_S, ld, N, M, false);
+    if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info));
+    HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n, c->d_S,
+                              ld, c->d_alpha, 1));
+    BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, n,
+                              c->d_S, ld, c->d_alpha, 1));
+    // cross-covariances for every grid point, one multi-RHS solve
+    double* KF;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)n * S * M, &KF));
+    svc_crosscov(s, c->d_x, c->d_ell, c->d_Lv, N, M, d_xs, tl_star, Ls, S, KF);
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_dgemv(c->blas, rocblas_operation_transpose, n, S * M, &one, KF, n, c->d_alpha, 1, &zero, d_mean,
+                              1));                                                   // mu_f = k_f^T Sigma^-1 y (:973)
+    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                              rocblas_diagonal_non_unit, n, S * M, &one, c->d_S, ld, KF, n));
+    col_sumsq(s, KF, n, n, S * M, d_colsq);
+    svc_predvar(s, Ls, d_colsq, S, M, c->d_pars + (P - 1), d_var);
+    HIP_TRY(c, hipMemcpyAsync(mean, d_mean, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(var, d_var, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (Lstar) HIP_TRY(c, hipMemcpyAsync(Lstar, Ls, (size_t)S * T * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_info[0] != 0)
+        return nmgp_fail(c, c->h_info[0], "covariance not positive definite (leading minor %d)", c->h_info[0]);
+    c->last_kind = 0;
+    return 0;
+}
+
+// shared by the separable and stationary predictors once K's lower triangle is in c->d_K and the starred
+// quantities are on the device
+static int eig_predict(nmgp_ctx* c, EigWork& w, double sigma2, int mode, const double* d_xs, const double* tl_star,
+                       const double* ts_star, double sig0, double l0, const double* d_kss, bool strict_clip, int S,
+                       double* mean, double* var) {
+    const int N = c->N, M = c->M;
+    hipStream_t s = c->stream;
+    double hs[4], loglik;
+    NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, false, hs, &loglik));       // a = projection of y (prediction.py:388)
+    double *KX, *Cq, *sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)N * S, &KX));
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, (size_t)N * S, &Cq));
+    NMGP_TRY(nmgp_scratch_get(c, SL_U, (size_t)2 * S * M + M, &sm));
+    double *d_mean = sm, *d_var = sm + (size_t)S * M, *d_Bdiag = d_var + (size_t)S * M;
+    std::vector<double> bd(M);
+    for (int m = 0; m < M; ++m) bd[m] = w.h_B[(size_t)m * M + m];
+    HIP_TRY(c, hipMemcpyAsync(d_Bdiag, bd.data(), M * sizeof(double), hipMemcpyHostToDevice, s));
+    sep_crossvec(s, mode, c->d_x, c->d_sig, c->d_ell, N, d_xs, tl_star, ts_star, sig0, l0, S, KX);
+    const double one = 1.0, zero = 0.0;
+    BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, N, S, N, &one, w.V, N, KX, N,
+                              &zero, Cq, N));
+    sep_predict(s, Cq, w.a, w.wB, w.VB, M, w.wK, N, sigma2, d_Bdiag, d_kss, strict_clip, S, d_mean, d_var);
+    HIP_TRY(c, hipMemcpyAsync(mean, d_mean, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(var, d_var, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int nmgp_predict_sep(nmgp_ctx* c, const double* pars, const double hyper[9], const double* xs, int S,
+                                double* mean, double* var) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars || !hyper || !xs || !mean || !var) return nmgp_fail(c, NMGP_E_NULL, "null argument");
+    if (S <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "S must be positive");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T;
+    const size_t P = (size_t)2 * N + T + 1;
+    hipStream_t s = c->stream;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_s = hyper[3], al_s = hyper[4], be_s = hyper[5];
+    const double sigma2 = std::exp(pars[P - 1]);
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    HIP_TRY(c, hipMemcpyAsync(c->d_pars, pars, P * sizeof(double), hipMemcpyHostToDevice, s));
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    double* sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)S * 6 + 16, &sm));
+    double *d_xs = sm, *proj = sm + S, *tl_star = proj + 2 * (size_t)S, *ts_star = tl_star + S, *d_kss = ts_star + S;
+    HIP_TRY(c, hipMemcpyAsync(d_xs, xs, (size_t)S * sizeof(double), hipMemcpyHostToDevice, s));
+    two_col_rhs(s, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
+    if (pl == ps) {
+        NMGP_TRY(gp_project(c, pl, d_xs, S, c->d_R, 2, proj));
+    } else {
+        NMGP_TRY(gp_project(c, pl, d_xs, S, c->d_R, 1, proj));
+        NMGP_TRY(gp_project(c, ps, d_xs, S, c->d_R + N, 1, proj + S));
+    }
+    sep_star(s, proj, S, mu_l, mu_s, tl_star, ts_star, d_kss);
+    EigWork w;
+    build_B(pars + 2 * N, M, true, w.h_L, w.h_B);
+    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    exp_vec(s, c->d_pars, N, c->d_ell);
+    exp_vec(s, c->d_pars + N, N, c->d_sig);
+    gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);
+    return eig_predict(c, w, sigma2, 0, d_xs, tl_star, ts_star, 0.0, 1.0, d_kss, false, S, mean, var);
+}
+
+extern "C" int nmgp_predict_sta(nmgp_ctx* c, const double* pars, const double* xs, int S, double* mean, double* var) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars || !xs || !mean || !var) return nmgp_fail(c, NMGP_E_NULL, "null argument");
+    if (S <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "S must be positive");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T;
+    hipStream_t s = c->stream;
+    const double l0 = std::exp(pars[0]), sig0 = std::exp(pars[1]);
+    const double sigma2 = std::exp(pars[T + 2]);
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    double* sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)S * 2 + 16, &sm));
+    double *d_xs = sm, *d_kss = sm + S;
+    HIP_TRY(c, hipMemcpyAsync(d_xs, xs, (size_t)S * sizeof(double), hipMemcpyHostToDevice, s));
+    fill_vec(s, d_kss, S, sig0 * sig0);                                   // sigma**2 * diag(B_f)  (prediction.py:1593)
+    EigWork w;
+    build_B(pars + 2, M, true, w.h_L, w.h_B);
+    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
+    NMGP_TRY(setup_small(c, w, M, N, sigma2));
+    rbf_cov_sym(s, c->d_x, N, sig0, l0, c->d_K, N, false);                // RBF_cov(x, alpha=sigma, beta=l) (:1587)
+    return eig_predict(c, w, sigma2, 1, d_xs, nullptr, nullptr, sig0, l0, d_kss, true, S, mean, var);
 }

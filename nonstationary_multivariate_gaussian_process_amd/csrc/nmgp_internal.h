@@ -71,7 +71,7 @@ struct nmgp_ctx {
     double* h_pin = nullptr;    // pinned host staging (scalars)
     int* h_info = nullptr;
     // generic scratch for the primitive entry points
-    DevBuf scratch[6];
+    DevBuf scratch[16];
     std::vector<PriorFactor> priors;
     // eigen path
     double* d_K = nullptr;      // [N, N] K_x then eigenvectors (separable / stationary)
@@ -87,6 +87,16 @@ struct nmgp_ctx {
 };
 
 int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...);
+// helpers shared between the translation units (defined in nmgp_api.hip)
+int nmgp_dev_alloc(nmgp_ctx* c, double** p, size_t nelem);
+int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out);
+int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out);
+int nmgp_ensure_S(nmgp_ctx* c);
+struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream
+    nmgp_ctx* c; int stage; hipEvent_t e0 = nullptr, e1 = nullptr;
+    NmgpStage(nmgp_ctx* ctx, int st);
+    ~NmgpStage();
+};
 
 #define HIP_TRY(ctx, expr)                                                                        \
     do {                                                                                          \
@@ -147,5 +157,40 @@ void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
                   double ig_const, int prior, double* out5);
 void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out);
+// ---- nmgp_kernels_eig.hip ----
+int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, const double* B, int m1, int m2,
+            double* out);
+void eig_reduce(hipStream_t s, double* a, const double* wB, int M, const double* wK, int N, const double* sigma2p,
+                bool scale, double* out);
+void colscale_d(hipStream_t s, const double* V, const double* wB, int M, const double* wK, int N, const double* sigma2p,
+                double* Vs);
+void colscale(hipStream_t s, const double* V, const double* svec, int rows, int cols, double* Vs);
+void sep_coreB(hipStream_t s, const double* At, const double* wB, int M, const double* wK, int N,
+               const double* sigma2p, double* coreB);
+void sep_adjoint(hipStream_t s, const double* x, const double* ell, const double* sig, const double* U,
+                 const double* wB, int M, const double* C, int N, double* part);
+void sep_grad_sum(hipStream_t s, const double* part, int NJ, int N, double* g);
+void exp_vec(hipStream_t s, const double* in, int n, double* out);
+void fill_vec(hipStream_t s, double* out, int n, double v);
+void two_col_rhs(hipStream_t s, const double* a, double mu_a, const double* b, double mu_b, int N, double* R);
+void sub_vec(hipStream_t s, const double* y, const double* mu, int n, double* out);
+void dot(hipStream_t s, const double* a, const double* b, int n, double* out);
+void kron_eigvec(hipStream_t s, const double* VB, int M, const double* VK, int N, double* U);
+void kron_w(hipStream_t s, const double* wB, int M, const double* wK, int N, double sigma2, double* w);
+void svc_crosscov(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M,
+                  const double* xs, const double* tl_star, const double* Lstar, int S, double* KF);
+void svc_star(hipStream_t st, const double* proj, int S, int M, double mu_l, double mu_L, double* tl_star,
+              double* Lstar);
+void svc_predvar(hipStream_t st, const double* Lstar, const double* colsq, int S, int M, const double* tse,
+                 double* var);
+void sep_crossvec(hipStream_t st, int mode, const double* x, const double* sig, const double* ell, int N,
+                  const double* xs, const double* tl_star, const double* ts_star, double sig0, double l0, int S,
+                  double* KX);
+void sep_predict(hipStream_t st, const double* Cq, const double* a, const double* wB, const double* VB, int M,
+                 const double* wK, int N, double sigma2, const double* Bdiag, const double* kss, bool strict_clip, int S,
+                 double* mean, double* var);
+void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_s, double* tl_star, double* ts_star,
+              double* kss);
+void add_diag(hipStream_t s, double* A, int ld, int n, double v);
 
 }  // namespace nmgpk

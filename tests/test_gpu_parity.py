@@ -165,3 +165,146 @@ def test_headline_size_properties(ctx):
     fm, _ = ctx.logpos_svc(g["pars"] - eps * v, g["hyper"], prior=False)
     fd = (fp[0] - fm[0]) / (2 * eps)
     assert abs(fd - glik @ v) / abs(fd) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# separable / stationary objectives, Kronecker primitives, prediction
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("sep_"))
+def test_sep_against_reference_golden(ctx, name):
+    g = golden(name)
+    ctx.set_data(g["x"], g["Y"])
+    out, grad = ctx.logpos_sep(g["pars"], g["hyper"], prior=bool(g["prior"]), want_grad=True)
+    assert relerr(out[0], g["out"][0]) < VAL_TOL, (out, g["out"])
+    assert relerr(out[1], g["out"][1]) < 1e-8          # eigen-trick likelihood
+    assert relerr(out[2:], g["out"][2:]) < VAL_TOL
+    assert relerr(out[4], g["out"][4]) < 1e-13         # Normal(0, c) incl. the float32 log(c) quirk
+    # the reference backpropagates through eigh (noisy at the jitter floor); ours is the analytic adjoint
+    assert vec_relerr(grad, g["grad"]) < 1e-4
+    out2, _ = ctx.logpos_sep(g["pars"], g["hyper"], prior=bool(g["prior"]), want_grad=False)
+    assert relerr(out2, out) < 1e-13
+
+
+@pytest.mark.parametrize("N,M,seed", [(1, 1, 0), (3, 2, 1), (65, 3, 2), (130, 5, 3), (257, 8, 4)])
+def test_sep_against_oracle_ragged_sizes(ctx, N, M, seed):
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from oracle import nmgp_oracle as O
+    d = sim.simulate_separable(N, M, seed)
+    pars = sim.perturb(d["pars_true"], 0.05, 0.2 * seed)
+    hv = [sim.HYPER_SEP[k] for k in SEP_KEYS]
+    ctx.set_data(d["x"], d["Y"])
+    out, grad = ctx.logpos_sep(pars, hv, prior=True, want_grad=True)
+    ref, gref = O.nlogpos_obj(pars, d["Y"], d["x"], **sim.HYPER_SEP, verbose=True, grad=True)
+    assert relerr(out[0], ref[0]) < VAL_TOL, (out, ref)
+    assert relerr(out[1], ref[1]) < 1e-8
+    assert vec_relerr(grad, gref) < GRAD_TOL
+    lik, glik = ctx.logpos_sep(pars, hv, prior=False, want_grad=True)
+    assert lik[0] == -lik[1]
+
+
+@pytest.mark.parametrize("name", golden_names("sta_"))
+def test_sta_against_reference_golden(ctx, name):
+    g = golden(name)
+    ctx.set_data(g["x"], g["Y"])
+    out, grad = ctx.logpos_sta(g["pars"], g["hyper"], prior=True, want_grad=True)
+    assert relerr(out, g["out"]) < 1e-8, (out, g["out"])
+    assert vec_relerr(grad, g["grad"]) < 1e-4
+    from oracle import nmgp_oracle as O
+    ref, gref = O.nlogpos_obj_S(g["pars"], g["Y"], g["x"], **hyper_dict(g["hyper"], STA_KEYS), verbose=True, grad=True)
+    assert vec_relerr(grad, gref) < 1e-7
+
+
+def test_kron_primitives_against_reference_golden(ctx):
+    g = golden("prims")
+    assert np.allclose(ctx.kron_mv(g["B"], g["K"], g["yk"]), g["kron_mv_sq"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(ctx.kron_mv(g["Br"], g["Kr"], g["yr"]), g["kron_mv_rect"], rtol=1e-12, atol=1e-12)
+    z = np.zeros(18)
+    s2 = float(g["sig2"])
+    assert relerr(ctx.mvn_logpdf_kron(g["yk"], z, g["B"], g["K"], s2), g["logpdf0"]) < 1e-10
+    assert relerr(ctx.mvn_logpdf_kron(g["yk"], None, g["B"], g["K"], s2, dense=True), g["logpdf2"]) < 1e-10
+    inv, ld = ctx.kron_inv_logdet(s2, g["B"], g["K"])
+    assert np.allclose(inv, g["kron_inv"], rtol=1e-9, atol=1e-11) and abs(ld - float(g["kron_logdet"])) < 1e-10
+    # the reference's smoke identity (distributions.py:162-169): logpdf0 == logpdf(y, 0, kron_logdet, kron_inv)
+    assert relerr(ctx.mvn_logpdf(g["yk"], z, ld, inv), g["logpdf"]) < 1e-10
+    # kron_mv == dense kron @ y on a bigger rectangular case (kronecker_operation.py:111-116)
+    rng = np.random.default_rng(5)
+    B, K, y = rng.standard_normal((5, 7)), rng.standard_normal((300, 513)), rng.standard_normal(7 * 513)
+    assert np.allclose(ctx.kron_mv(B, K, y), ctx.kron_product(B, K) @ y, rtol=1e-11, atol=1e-9)
+    B12 = rng.standard_normal((3, 12))
+    y12 = rng.standard_normal(12 * 513)
+    assert np.allclose(ctx.kron_mv(B12, K, y12), np.kron(B12, K) @ y12, rtol=1e-11, atol=1e-9)
+
+
+def test_python_mirror_sep_sta_and_primitives(ctx):
+    import torch
+    from nonstationary_multivariate_gaussian_process_amd import Utility as U
+    g = golden("sep_rngfree_N64_M3")
+    h = hyper_dict(g["hyper"], SEP_KEYS)
+    p = torch.from_numpy(g["pars"]).clone().requires_grad_(True)
+    out = U.logpos.nlogpos_obj(p, torch.from_numpy(g["Y"]), torch.from_numpy(g["x"]), **h, verbose=True)
+    assert len(out) == 6 and relerr([float(o.detach()) for o in out], g["out"]) < VAL_TOL
+    out[0].backward()
+    assert vec_relerr(p.grad.numpy(), g["grad"]) < 1e-4
+    g = golden("sta_rngfree_N64_M3")
+    h = hyper_dict(g["hyper"], STA_KEYS)
+    p = torch.from_numpy(g["pars"]).clone().requires_grad_(True)
+    out = U.logpos.nlogpos_obj_S(p, torch.from_numpy(g["Y"]), torch.from_numpy(g["x"]), h["mu_tilde_l"],
+                                 h["sigma_tilde_l"], a=h["a"], b=h["b"], c=h["c"], verbose=True)
+    assert len(out) == 5 and relerr([float(o.detach()) for o in out], g["out"]) < 1e-8
+    out[0].backward()
+    assert vec_relerr(p.grad.numpy(), g["grad"]) < 1e-4
+    gp = golden("prims")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    assert np.allclose(U.kronecker_operation.kron_mv(t(gp["Br"]), t(gp["Kr"]), t(gp["yr"])).numpy(), gp["kron_mv_rect"])
+    assert np.array_equal(U.kronecker_operation.kronecker_product_diag(t(gp["s1"]), t(gp["l2"])).numpy(), gp["kron_diag"])
+    s2 = torch.tensor(float(gp["sig2"]), dtype=torch.float64)
+    l0 = U.distributions.multivariate_normal_logpdf0(t(gp["yk"]), torch.zeros(18, dtype=torch.float64), t(gp["B"]),
+                                                     t(gp["K"]), s2)
+    inv = U.kronecker_operation.kron_inv(s2, t(gp["B"]), t(gp["K"]))
+    ld = U.kronecker_operation.kron_logdet(s2, t(gp["B"]), t(gp["K"]))
+    l1 = U.distributions.multivariate_normal_logpdf(t(gp["yk"]), torch.zeros(18, dtype=torch.float64), ld, inv)
+    assert relerr(float(l0), gp["logpdf0"]) < 1e-10 and relerr(float(l1), float(l0)) < 1e-10
+    assert relerr(float(U.distributions.inverse_gamma_logpdf(torch.tensor(0.3, dtype=torch.float64), 2.0, 0.7)),
+                  gp["invgamma"]) < 1e-14
+
+
+def test_prediction_against_reference_golden(ctx):
+    """North-star tolerance: predictive mean / variance within 1e-5 of the reference."""
+    import torch
+    from nonstationary_multivariate_gaussian_process_amd import Utility as U
+    g = golden("pred_N64_M3")
+    N, M = g["Y"].shape
+    T = M * (M + 1) // 2
+    ctx.set_data(g["x"], g["Y"])
+    mean, var, Ls = ctx.predict_svc(g["svc_pars"], g["svc_hyper"], g["xs"])
+    ref = g["svc_pct"]
+    assert np.allclose(mean, ref[:, 1], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, ((ref[:, 2] - ref[:, 1]) / 1.96) ** 2, rtol=1e-5, atol=1e-9)
+    assert np.allclose(Ls, g["svc_Lstar"], rtol=1e-6, atol=1e-9)
+    mean, var = ctx.predict_sep(g["sep_pars"], g["sep_hyper"], g["xs"])
+    ref = g["sep_pct"]
+    assert np.allclose(mean, ref[:, 1], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, ((ref[:, 2] - ref[:, 1]) / 1.96) ** 2, rtol=1e-5, atol=1e-9)
+    mean, var = ctx.predict_sta(g["sta_pars"], g["xs"])
+    assert np.allclose(mean, g["sta_mean"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, g["sta_std"] ** 2, rtol=1e-5, atol=1e-9)
+    # through the mirror, with the reference's signatures and return shapes
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    h = hyper_dict(g["svc_hyper"], SVC_KEYS)
+    p = g["svc_pars"]
+    pct, Lv = U.prediction.point_predmap_inhomogeneous(t(p[:N]), t(p[N:N + N * T]), t(p[-1:])[0], t(g["Y"]), t(g["x"]),
+                                                       t(g["xs"])[2], h["mu_tilde_l"], h["alpha_tilde_l"],
+                                                       h["beta_tilde_l"], h["mu_L"], h["alpha_L"], h["beta_L"])
+    assert pct.shape == (3, M) and Lv.shape == (T,)
+    assert np.allclose(pct.numpy(), g["svc_pct"][2], rtol=1e-5, atol=1e-7)
+    pw, Lg = U.prediction.pointwise_predmap_inhomogeneous(t(p[:N]), t(p[N:N + N * T]), t(p[-1:])[0], t(g["Y"]), t(g["x"]),
+                                                          t(g["xs"]), h["mu_tilde_l"], h["alpha_tilde_l"],
+                                                          h["beta_tilde_l"], h["mu_L"], h["alpha_L"], h["beta_L"])
+    assert pw.shape == (len(g["xs"]), 3, M) and np.allclose(pw.numpy(), g["svc_pct"], rtol=1e-5, atol=1e-7)
+    p = g["sta_pars"]
+    mu, sd = U.prediction.test_predmap_S(t(p[:1])[0], t(p[1:2])[0], t(p[2:2 + T]), t(p[-1:])[0], t(g["Y"]), t(g["x"]),
+                                         t(g["xs"]))
+    assert np.allclose(mu.numpy(), g["sta_mean"], rtol=1e-5, atol=1e-7) and np.allclose(sd.numpy(), g["sta_std"], rtol=1e-5)
+    pw = U.prediction.pointwise_predmap_S(t(p[:1])[0], t(p[1:2])[0], t(p[2:2 + T]), t(p[-1:])[0], t(g["Y"]), t(g["x"]),
+                                          t(g["xs"]))
+    assert np.allclose(pw.numpy(), g["sta_pct"], rtol=1e-5, atol=1e-7)
