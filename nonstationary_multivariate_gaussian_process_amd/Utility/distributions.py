@@ -8,7 +8,7 @@ from ._bridge import ctx, no_grad_inputs, to_np, scalar
 
 
 def _dt(v):
-    return torch.tensor(v).type(torch.DoubleTensor)
+    return torch.tensor(float(v), dtype=torch.float64)
 
 
 def multivariate_normal_logpdf(y, mu, logdetSigma, invSigma):

@@ -27,7 +27,7 @@ def kron_logdet(sigma2, B, K):
     """log det(sigma2 I + B kron K); reference kronecker_operation.py:57-69."""
     no_grad_inputs("kron_logdet", sigma2, B, K)
     _, ld = ctx().kron_inv_logdet(scalar(sigma2), to_np(B), to_np(K), want_inv=False)
-    return torch.tensor(ld).type(torch.DoubleTensor)
+    return torch.tensor(float(ld), dtype=torch.float64)
 
 
 def kron_mv(B, K, y):

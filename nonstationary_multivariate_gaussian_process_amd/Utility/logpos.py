@@ -97,8 +97,8 @@ class _FusedObjective(torch.autograd.Function):
             out, grad = np.full(nout, np.nan), (np.full(flat.shape[0], np.nan) if want_grad else None)
         fctx.shapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in pieces]
         fctx.grad_np = grad          # d NegLog / d pars
-        res = [torch.tensor(-out[0]).type(settings.torchType)]
-        res += [torch.tensor(v).type(settings.torchType) for v in out[1:]]
+        res = [torch.tensor(-float(out[0]), dtype=torch.float64)]
+        res += [torch.tensor(float(v), dtype=torch.float64) for v in out[1:]]
         fctx.mark_non_differentiable(*res[1:])
         return tuple(res)
 
@@ -122,7 +122,7 @@ class _FusedObjective(torch.autograd.Function):
 
 
 def _as_tensor(v):
-    return v if isinstance(v, torch.Tensor) else torch.tensor(float(v)).type(settings.torchType)
+    return v if isinstance(v, torch.Tensor) else torch.tensor(float(v), dtype=torch.float64)
 
 
 # ---- nonseparable ("SVC") model: reference logpos.py:299-380 ------------------------------------------
