@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--M", type=int, default=3)
     ap.add_argument("--grad", action="store_true", help="time value+gradient evaluations")
+    ap.add_argument("--workload", choices=["chain", "subjects"], default="chain",
+                    help="chain: one N=2048 chain per GPU (headline); subjects: BASELINE config 4, independent "
+                         "subjects of size --N sharded round-robin over the GPUs (8 per GPU), one stream each")
+    ap.add_argument("--subjects-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=3)
     a = ap.parse_args()
@@ -58,8 +62,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    from nonstationary_multivariate_gaussian_process_amd import _lib, chains, sim
 
+    if a.workload == "subjects":
+        return bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim)
     N, M = a.N, a.M
     n = N * M
     # one independent subject per rank: seed 2222 is the reference's single-subject seed (sim.py:359)
@@ -97,14 +103,10 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
 
-    stats = torch.tensor([elapsed, float(out[0]), 1.0], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats[1:], op=dist.ReduceOp.SUM)       # the reduction step of the per-subject chains
-        elapsed_max = float(tmax[0])
-    else:
-        elapsed_max = elapsed
+    elapsed_max = max_over_ranks(elapsed, world, torch, dist)
+    # the reduction step of the per-subject chains (RCCL all-reduce + all-gather of 8-double rows)
+    row = np.array([[rank, 1.0, a.steps] + [float(v) for v in out[:5]]])
+    chain_stats, chain_table = chains.reduce_rows(row, world, world, device="cuda")
     total_evals = a.steps * world
     value = total_evals / elapsed_max
 
@@ -130,6 +132,7 @@ def main():
             "config": {"workload": "nonseparable GP nlogpos_obj_SVC %s, D=%d, N=%d (MN=%d), one chain per GPU"
                                    % ("value+gradient" if want_grad else "value", M, N, n),
                        "stage_ms": stage_ms, "neglog_rank0": float(out[0]),
+                       "chains_ok": int(chain_stats[0]), "sum_neglog_all_chains": float(chain_stats[3]),
                        "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,
                        "cov_build_gbs": (cov_bytes / (cov_ms * 1e-3) / 1e9) if cov_ms > 0 else None},
             "roofline": {"kernel": "FP64 Cholesky of the %dx%d covariance (rocSOLVER dpotrf stage)" % (n, n),
@@ -140,6 +143,73 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(d, pars, hyper, a.cpu_evals, want_grad)
         print(json.dumps(rec), flush=True)
     ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def max_over_ranks(elapsed, world, torch, dist):
+    if world == 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
+    """BASELINE config 4 (Nonseparable_model_mpisim-style): subjects_per_gpu x world independent subjects, D=M, N=--N
+    (default there: 1024), subject s on rank s mod world, one context (= one HIP stream) per subject so that the
+    factorisations of different subjects overlap on the GPU.  A step = one evaluation of EVERY local subject."""
+    N, M = a.N, a.M
+    n_subj = a.subjects_per_gpu * world
+    mine = chains.partition(n_subj, world, rank)
+    hyper = sim.HYPER_SVC_MPISIM
+    hv = np.array([hyper[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a",
+                                      "b")], dtype=np.float64)
+    ctxs = []
+    for s_id in mine:
+        d = sim.simulate_nonseparable(N, M, seed=s_id)       # subject s uses seed s (sim.py:361-363)
+        c = _lib.Context(local_rank)
+        c.set_data(d["x"], d["Y"])
+        c.svc_set_pars(sim.perturb(d["pars_true"], 0.05, 0.7))
+        ctxs.append(c)
+    want_grad = bool(a.grad)
+
+    def step():
+        for c in ctxs:
+            c.svc_eval_resident(hv, True, want_grad)
+        return [c.svc_fetch(False)[0] for c in ctxs]
+
+    for _ in range(a.warmup):
+        outs = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        outs = step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, torch, dist)
+    rows = np.array([[s_id, 1.0, a.steps] + [float(v) for v in o[:5]] for s_id, o in zip(mine, outs)])
+    stats, table = chains.reduce_rows(rows, n_subj, world, device="cuda")
+    if rank == 0:
+        total = a.steps * n_subj
+        print(json.dumps({
+            "metric": "log-posterior evals/sec (%d subjects, N=%d, D=%d nonseparable GP)" % (n_subj, N, M),
+            "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d independent subjects (%d per GPU, one stream each), nlogpos_obj_SVC %s, D=%d, "
+                                   "N=%d" % (n_subj, a.subjects_per_gpu, "value+gradient" if want_grad else "value", M, N),
+                       "subjects_ok": int(stats[0]), "sum_neglog": float(stats[3])}}), flush=True)
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
