@@ -135,6 +135,14 @@ int nmgp_mvn_logpdf_dense(nmgp_ctx* ctx, const double* y, const double* mu, cons
 int nmgp_kron_inv_logdet(nmgp_ctx* ctx, double sigma2, const double* B, int M, const double* K, int N,
                          double* out_inv, double* out_logdet);
 
+/* Cholesky factorisation A = L L^T of a symmetric positive definite [n,n] matrix (torch.cholesky as used at
+ * prediction.py:974; also the entry through which the custom blocked factorisation of the log-posterior path is
+ * tested on its own).  out_L: [n,n] row-major with the factor in the UPPER triangle == column-major lower (i.e.
+ * out_L^T is the usual lower factor; the other triangle holds the input's values).  rhs (optional, [n]) is carried
+ * through the factorisation as an extra row: out_z = L^-1 rhs.  algo: 1 = custom gfx950 factorisation, 0 = rocSOLVER. */
+int nmgp_cholesky(nmgp_ctx* ctx, const double* A, int n, const double* rhs, double* out_L, double* out_z,
+                  int algo);
+
 /* ---- deterministic prediction (prediction.py:912-988, 337-408, 1566-1638) -------------------- */
 /* Nonseparable: predictive mean / variance of y at S new inputs xs given MAP parameters.
  * mean, var: [S,M]; Lstar: [S,T] (predicted L_vec at xs, exp already applied on the diagonal slots). */

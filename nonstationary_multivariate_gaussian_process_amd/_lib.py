@@ -51,6 +51,7 @@ SIGNATURES = {
     "nmgp_mvn_logpdf_kron": (I, [V, P, P, P, I, P, I, D, P]),
     "nmgp_mvn_logpdf_dense": (I, [V, P, P, P, I, P, I, D, P]),
     "nmgp_kron_inv_logdet": (I, [V, D, P, I, P, I, P, P]),
+    "nmgp_cholesky": (I, [V, P, I, P, P, P, I]),
     "nmgp_predict_svc": (I, [V, P, P, P, I, P, P, P]),
     "nmgp_predict_sep": (I, [V, P, P, P, I, P, P]),
     "nmgp_predict_sta": (I, [V, P, P, I, P, P]),
@@ -298,6 +299,17 @@ class Context:
         self.check(self.lib.nmgp_kron_inv_logdet(self.h, float(sigma2), ptr(B), B.shape[0], ptr(K), K.shape[0], ptr(inv),
                                                  ptr(ld)))
         return inv, float(ld[0])
+
+    def cholesky(self, A, rhs=None, algo=1):
+        """Lower Cholesky factor of the SPD matrix A (and L^-1 rhs when rhs is given)."""
+        A = as_f64(A)
+        n = A.shape[0]
+        rhsa = None if rhs is None else as_f64(rhs).reshape(-1)
+        out = np.empty((n, n))
+        z = np.empty(n) if rhsa is not None else None
+        self.check(self.lib.nmgp_cholesky(self.h, ptr(A), n, ptr(rhsa), ptr(out), ptr(z), int(algo)))
+        L = np.tril(out.T)           # the library's column-major lower triangle == row-major upper
+        return (L, z) if rhsa is not None else L
 
     # -- prediction -----------------------------------------------------------------------------
     def predict_svc(self, pars, hyper, xs):

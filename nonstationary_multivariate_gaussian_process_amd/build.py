@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libnmgp_hip.so")
-SOURCES = ["nmgp_kernels.hip", "nmgp_kernels_eig.hip", "nmgp_api.hip", "nmgp_eig.hip"]
+SOURCES = ["nmgp_kernels.hip", "nmgp_kernels_eig.hip", "nmgp_chol.hip", "nmgp_api.hip", "nmgp_eig.hip"]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
          "-I" + INCLUDE, "-I" + CSRC]

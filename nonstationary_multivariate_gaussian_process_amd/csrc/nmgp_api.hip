@@ -127,6 +127,11 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     nmgp_ctx* c = new nmgp_ctx();
     c->device = device;
     *out = c;   // returned even on failure below so that nmgp_last_error() is reachable
+    if (const char* e = std::getenv("NMGP_CHOL")) c->chol_algo = (std::strcmp(e, "rocsolver") == 0) ? 0 : 1;
+    if (const char* e = std::getenv("NMGP_CHOL_NB1")) {
+        int v = std::atoi(e);
+        if (v >= 64) c->chol_nb1 = (v / 64) * 64;
+    }
     HIP_TRY(c, hipSetDevice(device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
@@ -218,11 +223,12 @@ extern "C" int nmgp_set_data(nmgp_ctx* c, const double* x, const double* Y, int 
 
 int nmgp_ensure_S(nmgp_ctx* c) {
     const size_t n = c->n;
-    if (!c->d_S || c->S_cap < n * n) {
-        NMGP_TRY(nmgp_dev_alloc(c, &c->d_S, n * n));
-        c->S_cap = n * n;
+    const size_t ld = ((n + 1 + 15) / 16) * 16;      // one extra row (the right-hand side rides below the matrix), even ld
+    if (!c->d_S || c->S_cap < ld * n) {
+        NMGP_TRY(nmgp_dev_alloc(c, &c->d_S, ld * n));
+        c->S_cap = ld * n;
     }
-    c->ldS = c->n;
+    c->ldS = (int)ld;
     return 0;
 }
 
@@ -295,19 +301,36 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (P - 1), c->d_S, ld, N, M, false);
         if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     }
-    {
-        StageScope sp(c, NMGP_STAGE_CHOL);
-        BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info));
-    }
-    {
-        StageScope sp(c, NMGP_STAGE_SOLVE);
-        HIP_TRY(c, hipMemcpyAsync(c->d_z, c->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n,
-                                  c->d_S, ld, c->d_z, 1));
-        if (want_grad) {
-            HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-            BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
-                                      rocblas_diagonal_non_unit, n, c->d_S, ld, c->d_alpha, 1));
+    if (c->chol_algo == 1) {
+        {
+            StageScope sp(c, NMGP_STAGE_CHOL);
+            set_row(s, c->d_S, ld, n, c->d_y, n);                       // y rides along as row n
+            potrf_lower(s, c->d_S, ld, n, 1, c->chol_nb1, c->d_info);   // row n becomes z = L^-1 y
+        }
+        {
+            StageScope sp(c, NMGP_STAGE_SOLVE);
+            get_row(s, c->d_S, ld, n, c->d_z, n);
+            if (want_grad) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+                BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
+                                          rocblas_diagonal_non_unit, n, c->d_S, ld, c->d_alpha, 1));
+            }
+        }
+    } else {
+        {
+            StageScope sp(c, NMGP_STAGE_CHOL);
+            BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info));
+        }
+        {
+            StageScope sp(c, NMGP_STAGE_SOLVE);
+            HIP_TRY(c, hipMemcpyAsync(c->d_z, c->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n,
+                                      c->d_S, ld, c->d_z, 1));
+            if (want_grad) {
+                HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+                BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
+                                          rocblas_diagonal_non_unit, n, c->d_S, ld, c->d_alpha, 1));
+            }
         }
     }
     {
@@ -424,8 +447,53 @@ extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out)
     svc_prep(s, c->d_pars, c->N, c->M, c->d_ell, c->d_Lv);
     int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (c->P_svc - 1), c->d_S, c->ldS, c->N, c->M, true);
     if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", c->M);
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_S, (size_t)c->n * c->n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)c->n * sizeof(double), c->d_S, (size_t)c->ldS * sizeof(double),
+                                (size_t)c->n * sizeof(double), (size_t)c->n, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+// Cholesky primitive (torch.cholesky analogue; prediction.py:974 uses it) and the developer entry for the custom
+// factorisation: factors the symmetric positive definite A (lower triangle of the row-major == column-major
+// symmetric matrix is read), optionally carrying a right-hand side.
+extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* rhs, double* out_L, double* out_z,
+                             int algo) {
+    if (!c) return NMGP_E_NULL;
+    if (!A || !out_L) return nmgp_fail(c, NMGP_E_NULL, "A/out_L must not be NULL");
+    if (n <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "n must be positive");
+    if (rhs && !out_z) return nmgp_fail(c, NMGP_E_NULL, "out_z must not be NULL when rhs is given");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t ld = (((size_t)n + 1 + 15) / 16) * 16;
+    double *dA, *dv;
+    NMGP_TRY(nmgp_scratch_get(c, 2, ld * n, &dA));
+    NMGP_TRY(nmgp_scratch_get(c, 3, (size_t)2 * n + 8, &dv));
+    HIP_TRY(c, hipMemsetAsync(dA, 0, ld * n * sizeof(double), s));
+    HIP_TRY(c, hipMemcpy2DAsync(dA, ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                                (size_t)n, hipMemcpyHostToDevice, s));
+    if (rhs) HIP_TRY(c, hipMemcpyAsync(dv, rhs, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_info + 5, 0, sizeof(int), s));
+    if (algo == 1) {
+        StageScope sp(c, NMGP_STAGE_CHOL);
+        if (rhs) set_row(s, dA, (int)ld, n, dv, n);
+        potrf_lower(s, dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5);
+        if (rhs) get_row(s, dA, (int)ld, n, dv + n, n);
+    } else {
+        StageScope sp(c, NMGP_STAGE_CHOL);
+        BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, dA, (int)ld, c->d_info + 5));
+        if (rhs) {
+            HIP_TRY(c, hipMemcpyAsync(dv + n, dv, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n,
+                                      dA, (int)ld, dv + n, 1));
+        }
+    }
+    HIP_TRY(c, hipMemcpy2DAsync(out_L, (size_t)n * sizeof(double), dA, ld * sizeof(double), (size_t)n * sizeof(double),
+                                (size_t)n, hipMemcpyDeviceToHost, s));
+    if (rhs) HIP_TRY(c, hipMemcpyAsync(out_z, dv + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_info + 5, c->d_info + 5, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_info[5] != 0)
+        return nmgp_fail(c, c->h_info[5], "matrix is not positive definite (leading minor %d)", c->h_info[5]);
     return 0;
 }
 

@@ -1,0 +1,280 @@
+// Custom blocked FP64 Cholesky for gfx950 (replaces rocSOLVER dpotrf on the log-posterior path, which spends
+// 20 ms in ~700 tiny launches on a 6144^2 matrix).
+//
+//   * right-looking, two-level blocking: 64-wide diagonal steps inside NB1-wide outer panels, so that the big
+//     trailing update runs with K = NB1 (compute bound) while the panel-internal updates stay narrow;
+//   * the right-hand side y rides along as an EXTRA ROW below the matrix (row n of the augmented array):
+//     the panel solves and trailing updates turn it into z = L^-1 y, so no separate triangular solve is needed
+//     (the reference needs Sigma^-1 y and log det Sigma only: logpos.py:352-354);
+//   * k_syrk_lower: C -= A A^T on the lower trapezoid with v_mfma_f64_16x16x4_f64, 128x128 tile per workgroup,
+//     4 waves x (4x4) MFMA tiles, k-panels of 16 staged through LDS (double buffered, register prefetch).  The MFMA
+//     takes the j-side fragment as its A operand and the i-side fragment as B, so that lanes 0..15 of the result
+//     hold 16 consecutive ROWS of C: every store segment is 128 contiguous bytes of a column-major column;
+//   * k_potf2_64: one workgroup factors a 64x64 diagonal block in LDS (one barrier per column);
+//   * k_trsm_64: X L^T = A for 64 rows per workgroup, four lanes per row with the partial dot products combined by
+//     DPP quad permutes (no LDS round trip), rows of A kept in registers.
+//
+// All matrices column-major, lower triangle; leading dimensions must be even (16-byte vector loads).
+#include "nmgp_internal.h"
+
+namespace nmgpk {
+
+static inline int cdiv_c(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define SY_BM 128
+#define SY_BK 16
+#define SY_LD (SY_BM + 16)
+
+__device__ inline double2 load2_guard(const double* __restrict__ p, int r, int rows) {
+    double2 v;
+    if (r + 1 < rows) {
+        v = *reinterpret_cast<const double2*>(p);
+    } else {
+        v.x = (r < rows) ? p[0] : 0.0;
+        v.y = 0.0;
+    }
+    return v;
+}
+
+// C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
+__global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C,
+                                                        int ldc, int mrows, int ncols, int K) {
+    __shared__ double sA[2][SY_BK * SY_LD];
+    __shared__ double sB[2][SY_BK * SY_LD];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bi < bj) return;
+    const bool diag = (bi == bj);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int row0 = bi * SY_BM, col0 = bj * SY_BM;
+    const int rp = tid & 63, cg = tid >> 6;
+    double2 ra[4], rb[4];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kc = k0 + cg + 4 * q;
+            const int ri = row0 + 2 * rp, rj = col0 + 2 * rp;
+            if (kc < K) {
+                ra[q] = load2_guard(A + (size_t)kc * lda + ri, ri, mrows);
+                if (!diag) rb[q] = load2_guard(A + (size_t)kc * lda + rj, rj, mrows);
+            } else {
+                ra[q] = make_double2(0.0, 0.0);
+                rb[q] = make_double2(0.0, 0.0);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kc = cg + 4 * q;
+            *reinterpret_cast<double2*>(&sA[buf][kc * SY_LD + 2 * rp]) = ra[q];
+            if (!diag) *reinterpret_cast<double2*>(&sB[buf][kc * SY_LD + 2 * rp]) = rb[q];
+        }
+    };
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // a wave whose 64x64 sub-tile lies strictly above the diagonal has nothing to compute
+    const bool active = !(diag && wi < wj);
+    const int nk = (K + SY_BK - 1) / SY_BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * SY_BK);
+        if (active) {
+            const double* tA = sA[cur];
+            const double* tB = diag ? sA[cur] : sB[cur];
+#pragma unroll
+            for (int kk = 0; kk < SY_BK / 4; ++kk) {
+                const int k = kk * 4 + (lane >> 4);
+                double fa[4], fb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    fa[t] = tA[k * SY_LD + wi * 64 + t * 16 + (lane & 15)];
+                    fb[t] = tB[k * SY_LD + wj * 64 + t * 16 + (lane & 15)];
+                }
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti)
+                        acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tj], fa[ti], acc[tj][ti], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    // D[row = (lane>>4) + 4 reg  <-> j][col = lane&15 <-> i]
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
+                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
+                if (i < mrows && j < ncols && i >= j) {
+                    double* p = C + (size_t)j * ldc + i;
+                    *p = *p - acc[tj][ti][r];
+                }
+            }
+}
+
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K) {
+    if (mrows <= 0 || ncols <= 0 || K <= 0) return;
+    dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM));
+    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
+// info receives (goff + c + 1) for the first non-positive pivot c (LAPACK convention), left untouched otherwise.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
+                                                   int goff) {
+    __shared__ double S[64][65];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx & 63, c = idx >> 6;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
+        S[r][c] = v;
+    }
+    const int r = tid & 63, g = tid >> 6;
+    for (int c = 0; c < nb; ++c) {
+        __syncthreads();
+        const double dcc = S[c][c];
+        if (!(dcc > 0.0) && tid == 0) atomicCAS(info, 0, goff + c + 1);
+        const double d = sqrt(dcc), rinv = 1.0 / d;
+        const double lr = S[r][c] * rinv;
+        if (g == 0 && r >= c && r < nb) A[(size_t)c * lda + r] = (r == c) ? d : lr;
+        for (int cc = c + 1 + g; cc <= r; cc += 4) S[r][cc] -= lr * (S[cc][c] * rinv);
+    }
+}
+
+void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff) {
+    hipLaunchKernelGGL(k_potf2_64, dim3(1), dim3(256), 0, s, A, lda, nb, info, goff);
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel solve  X L^T = A  (L: nb x nb lower, nb <= 64; A: rows x nb, overwritten by X)
+// four lanes per row: lane g of a row owns columns k = 4 kk + g in registers; the dot product of step c is split
+// over the four lanes and combined with two DPP quad permutes.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double quad_xor_add(double v, int which) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2, hi2;
+    if (which == 1) {
+        lo2 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        hi2 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    } else {
+        lo2 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        hi2 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+    }
+    return v + __hiloint2double(hi2, lo2);
+}
+
+__global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, int ldl, int nb, double* __restrict__ A,
+                                                  int lda, int rows) {
+    __shared__ double Lm[64][65];
+    __shared__ double rinv[64];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx & 63, c = idx >> 6;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = L[(size_t)c * ldl + r];
+        Lm[r][c] = v;
+    }
+    __syncthreads();
+    if (tid < 64) rinv[tid] = 1.0 / Lm[tid][tid];
+    __syncthreads();
+    const int lr = tid >> 2, g = tid & 3;
+    const int row = blockIdx.x * 64 + lr;
+    const bool valid = row < rows;
+    double x[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + g;
+        x[kk] = (valid && k < nb) ? A[(size_t)k * lda + row] : 0.0;
+    }
+#pragma unroll
+    for (int kc = 0; kc < 16; ++kc) {
+#pragma unroll
+        for (int gc = 0; gc < 4; ++gc) {
+            const int c = 4 * kc + gc;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk <= kc; ++kk) {
+                const int k = 4 * kk + g;
+                const bool use = (kk < kc) || (g < gc);
+                const double t = use ? x[kk] * Lm[c][k] : 0.0;
+                if (kk & 1) s1 += t; else s0 += t;
+            }
+            double sdot = s0 + s1;
+            sdot = quad_xor_add(sdot, 1);
+            sdot = quad_xor_add(sdot, 2);
+            if (g == gc) x[kc] = (x[kc] - sdot) * rinv[c];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + g;
+        if (valid && k < nb) A[(size_t)k * lda + row] = x[kk];
+    }
+}
+
+void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64)), dim3(256), 0, s, L, ldl, nb, A, lda, rows);
+}
+
+// A[row, j] = v[j]  (the extra row carrying the right-hand side)
+__global__ void k_set_row(double* __restrict__ A, int lda, int row, const double* __restrict__ v, int n) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) A[(size_t)j * lda + row] = v[j];
+}
+void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n) {
+    hipLaunchKernelGGL(k_set_row, dim3(cdiv_c(n, 256)), dim3(256), 0, s, A, lda, row, v, n);
+}
+__global__ void k_get_row(const double* __restrict__ A, int lda, int row, double* __restrict__ v, int n) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) v[j] = A[(size_t)j * lda + row];
+}
+void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n) {
+    hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256)), dim3(256), 0, s, A, lda, row, v, n);
+}
+
+// Blocked Cholesky of the n x n lower triangle of A with `extra` additional rows below it (rows n .. n+extra-1 of
+// the same array) that are carried through the panel solves and updates: on exit they hold  R L^-T.
+void potrf_lower(hipStream_t s, double* A, int lda, int n, int extra, int nb1, int* info) {
+    const int m = n + extra;
+    for (int c0 = 0; c0 < n; c0 += nb1) {
+        const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
+        for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
+            const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
+            double* Ajj = A + (size_t)j0 * lda + j0;
+            potf2_64(s, Ajj, lda, jb, info, j0);
+            const int below = m - (j0 + jb);
+            if (below > 0) {
+                double* Apan = A + (size_t)j0 * lda + (j0 + jb);
+                trsm_64(s, Ajj, lda, jb, Apan, lda, below);
+                const int ncols = c0 + w1 - (j0 + jb);
+                if (ncols > 0) syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb);
+            }
+        }
+        const int c1 = c0 + w1;
+        if (c1 < n)
+            syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1);
+    }
+}
+
+}  // namespace nmgpk

@@ -82,6 +82,8 @@ struct nmgp_ctx {
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
 
+    int chol_algo = 1;          // 0 = rocSOLVER dpotrf + rocBLAS dtrsv, 1 = custom blocked factorisation (nmgp_chol.hip)
+    int chol_nb1 = 512;         // outer panel width of the custom factorisation
     bool profiling = false;
     StageTimer timers[NMGP_STAGE_COUNT];
 };
@@ -192,5 +194,12 @@ void sep_predict(hipStream_t st, const double* Cq, const double* a, const double
 void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_s, double* tl_star, double* ts_star,
               double* kss);
 void add_diag(hipStream_t s, double* A, int ld, int n, double v);
+// ---- nmgp_chol.hip ----
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K);
+void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff);
+void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows);
+void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n);
+void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n);
+void potrf_lower(hipStream_t s, double* A, int lda, int n, int extra, int nb1, int* info);
 
 }  // namespace nmgpk
