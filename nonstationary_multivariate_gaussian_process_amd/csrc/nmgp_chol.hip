@@ -113,20 +113,28 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
         __syncthreads();
     }
     if (!active) return;
-    // D[row = (lane>>4) + 4 reg  <-> j][col = lane&15 <-> i]
+    // D[row = (lane>>4) + 4 reg  <-> j][col = lane&15 <-> i].  The 16 read-modify-writes of one tj row are issued as
+    // 16 loads followed by 16 stores (a load/store/load/... sequence would serialise on memory latency).
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < 4; ++tj) {
+        double cv[4][4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
                 const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
-                if (i < mrows && j < ncols && i >= j) {
-                    double* p = C + (size_t)j * ldc + i;
-                    *p = *p - acc[tj][ti][r];
-                }
+                cv[ti][r] = (i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
+                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
+                if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = cv[ti][r] - acc[tj][ti][r];
+            }
+    }
 }
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K) {
@@ -139,25 +147,71 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
 // 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
 // info receives (goff + c + 1) for the first non-positive pivot c (LAPACK convention), left untouched otherwise.
 // ---------------------------------------------------------------------------------------------
+template <int KC, int GC>
+__device__ __forceinline__ void potf2_step(double (&a)[16], double (*colbuf)[64], double* __restrict__ A, int lda, int nb,
+                                  int* __restrict__ info, int goff, int r, int g, int tid) {
+    constexpr int c = 4 * KC + GC;
+    if (c >= nb) return;                                     // uniform
+    double* cb = colbuf[c & 1];
+    if (g == GC) cb[r] = a[KC];
+    __syncthreads();
+    // branch-free body: all broadcast reads are issued unconditionally (hipcc otherwise wraps every predicated LDS
+    // read in its own exec-mask branch with a full lgkmcnt wait: 16 serialised round trips per column)
+    const double piv = cb[c];
+    const double mine = cb[r];
+    double t[16];
+#pragma unroll
+    for (int kk = KC; kk < 16; ++kk) t[kk] = cb[4 * kk + g];
+    if (!(piv > 0.0) && tid == 0) atomicCAS(info, 0, goff + c + 1);
+    const double rinv = rsqrt(piv);
+    const double lr = mine * rinv;
+    // the finished column stays in the owner's registers and is written to memory once, after the last column
+    // (a global store inside the loop would make every barrier wait for its acknowledgement)
+    {
+        const double fin = (r == c) ? (piv * rinv) : lr;
+        a[KC] = (g == GC && r >= c) ? fin : a[KC];
+    }
+#pragma unroll
+    for (int kk = KC; kk < 16; ++kk) {
+        const int cc = 4 * kk + g;
+        const double upd = a[kk] - lr * (t[kk] * rinv);
+        const bool on = (kk > KC || g > GC) && (cc <= r);
+        a[kk] = on ? upd : a[kk];
+    }
+}
+
+template <int KC>
+__device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[64], double* __restrict__ A, int lda, int nb,
+                                    int* __restrict__ info, int goff, int r, int g, int tid) {
+    potf2_step<KC, 0>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
+    potf2_step<KC, 1>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
+    potf2_step<KC, 2>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
+    potf2_step<KC, 3>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
+}
+
 __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
                                                    int goff) {
-    __shared__ double S[64][65];
+    // thread (r, g): row r = tid & 63, column class g = tid >> 6 (wave-uniform); it keeps S[r][4 kk + g], kk = 0..15,
+    // in registers.  Per column: the owning wave publishes the column through LDS (double buffered), one barrier,
+    // every thread forms the pivot's reciprocal square root and updates its registers.
+    __shared__ double colbuf[2][64];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx & 63, c = idx >> 6;
+    const int r = tid & 63, g = tid >> 6;
+    double a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int c = 4 * kk + g;
         double v = (r == c) ? 1.0 : 0.0;
         if (r < nb && c <= r) v = A[(size_t)c * lda + r];
-        S[r][c] = v;
+        a[kk] = v;
     }
-    const int r = tid & 63, g = tid >> 6;
-    for (int c = 0; c < nb; ++c) {
-        __syncthreads();
-        const double dcc = S[c][c];
-        if (!(dcc > 0.0) && tid == 0) atomicCAS(info, 0, goff + c + 1);
-        const double d = sqrt(dcc), rinv = 1.0 / d;
-        const double lr = S[r][c] * rinv;
-        if (g == 0 && r >= c && r < nb) A[(size_t)c * lda + r] = (r == c) ? d : lr;
-        for (int cc = c + 1 + g; cc <= r; cc += 4) S[r][cc] -= lr * (S[cc][c] * rinv);
+#define PF(K) potf2_steps4<K>(a, colbuf, A, lda, nb, info, goff, r, g, tid)
+    PF(0); PF(1); PF(2); PF(3); PF(4); PF(5); PF(6); PF(7); PF(8); PF(9); PF(10); PF(11); PF(12); PF(13); PF(14); PF(15);
+#undef PF
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int c = 4 * kk + g;
+        if (r < nb && c <= r) A[(size_t)c * lda + r] = a[kk];
     }
 }
 
@@ -170,17 +224,40 @@ void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff) {
 // four lanes per row: lane g of a row owns columns k = 4 kk + g in registers; the dot product of step c is split
 // over the four lanes and combined with two DPP quad permutes.
 // ---------------------------------------------------------------------------------------------
-__device__ inline double quad_xor_add(double v, int which) {
+template <int SRC>
+__device__ inline double quad_bcast(double v) {
+    // value of lane (4 q + SRC) for every lane of quad q: DPP quad_perm [SRC, SRC, SRC, SRC]
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
     int lo = __double2loint(v), hi = __double2hiint(v);
-    int lo2, hi2;
-    if (which == 1) {
-        lo2 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        hi2 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
-    } else {
-        lo2 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        hi2 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int KC, int GC>
+__device__ __forceinline__ void trsm_step(double (&x)[16], const double (*Lm)[65], const double* rinv, int g) {
+    constexpr int c = 4 * KC + GC;
+    // owner lane (g == GC) finalises column c, the quad receives it, everyone retires column c from its own columns
+    double xc = x[KC] * rinv[c];
+    xc = quad_bcast<GC>(xc);
+    if (g == GC) x[KC] = xc;
+    double t[16];
+#pragma unroll
+    for (int kk = KC; kk < 16; ++kk) t[kk] = Lm[4 * kk + g][c];      // unconditional reads (see k_potf2_64)
+    {
+        const double upd = x[KC] - xc * t[KC];
+        x[KC] = (g > GC) ? upd : x[KC];
     }
-    return v + __hiloint2double(hi2, lo2);
+#pragma unroll
+    for (int kk = KC + 1; kk < 16; ++kk) x[kk] -= xc * t[kk];
+}
+
+template <int KC>
+__device__ __forceinline__ void trsm_steps4(double (&x)[16], const double (*Lm)[65], const double* rinv, int g) {
+    trsm_step<KC, 0>(x, Lm, rinv, g);
+    trsm_step<KC, 1>(x, Lm, rinv, g);
+    trsm_step<KC, 2>(x, Lm, rinv, g);
+    trsm_step<KC, 3>(x, Lm, rinv, g);
 }
 
 __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, int ldl, int nb, double* __restrict__ A,
@@ -206,25 +283,12 @@ __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, i
         const int k = 4 * kk + g;
         x[kk] = (valid && k < nb) ? A[(size_t)k * lda + row] : 0.0;
     }
-#pragma unroll
-    for (int kc = 0; kc < 16; ++kc) {
-#pragma unroll
-        for (int gc = 0; gc < 4; ++gc) {
-            const int c = 4 * kc + gc;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int kk = 0; kk <= kc; ++kk) {
-                const int k = 4 * kk + g;
-                const bool use = (kk < kc) || (g < gc);
-                const double t = use ? x[kk] * Lm[c][k] : 0.0;
-                if (kk & 1) s1 += t; else s0 += t;
-            }
-            double sdot = s0 + s1;
-            sdot = quad_xor_add(sdot, 1);
-            sdot = quad_xor_add(sdot, 2);
-            if (g == gc) x[kc] = (x[kc] - sdot) * rinv[c];
-        }
-    }
+    trsm_steps4<0>(x, Lm, rinv, g);   trsm_steps4<1>(x, Lm, rinv, g);   trsm_steps4<2>(x, Lm, rinv, g);
+    trsm_steps4<3>(x, Lm, rinv, g);   trsm_steps4<4>(x, Lm, rinv, g);   trsm_steps4<5>(x, Lm, rinv, g);
+    trsm_steps4<6>(x, Lm, rinv, g);   trsm_steps4<7>(x, Lm, rinv, g);   trsm_steps4<8>(x, Lm, rinv, g);
+    trsm_steps4<9>(x, Lm, rinv, g);   trsm_steps4<10>(x, Lm, rinv, g);  trsm_steps4<11>(x, Lm, rinv, g);
+    trsm_steps4<12>(x, Lm, rinv, g);  trsm_steps4<13>(x, Lm, rinv, g);  trsm_steps4<14>(x, Lm, rinv, g);
+    trsm_steps4<15>(x, Lm, rinv, g);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
         const int k = 4 * kk + g;
