@@ -133,7 +133,9 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
         if (v >= 64) c->chol_nb1 = (v / 64) * 64;
     }
     HIP_TRY(c, hipSetDevice(device));
+    if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
     BLAS_TRY(c, rocblas_set_stream(c->blas, c->stream));
     BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
@@ -169,6 +171,11 @@ extern "C" int nmgp_ctx_destroy(nmgp_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_info) hipHostFree(c->h_info);
     if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->stream2) {
+        hipStreamSynchronize(c->stream2);
+        hipStreamDestroy(c->stream2);
+    }
+    for (auto e : c->chol_ev) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -268,6 +275,18 @@ int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
     return 0;
 }
 
+// events for the look-ahead factorisation (created once, reused by every evaluation)
+static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
+    if (!c->chol_lookahead) return nullptr;
+    const size_t need = 2 * (size_t)((n + c->chol_nb1 - 1) / c->chol_nb1) + 3;
+    while (c->chol_ev.size() < need) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->chol_ev.push_back(e);
+    }
+    return c->chol_ev.data();
+}
+
 // ---- nonseparable objective --------------------------------------------------------------------
 static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_grad) {
     if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
@@ -305,7 +324,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         {
             StageScope sp(c, NMGP_STAGE_CHOL);
             set_row(s, c->d_S, ld, n, c->d_y, n);                       // y rides along as row n
-            potrf_lower(s, c->d_S, ld, n, 1, c->chol_nb1, c->d_info);   // row n becomes z = L^-1 y
+            potrf_lower(s, c->stream2, chol_events(c, n), c->d_S, ld, n, 1, c->chol_nb1, c->d_info);   // row n -> L^-1 y
         }
         {
             StageScope sp(c, NMGP_STAGE_SOLVE);
@@ -476,7 +495,7 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     if (algo == 1) {
         StageScope sp(c, NMGP_STAGE_CHOL);
         if (rhs) set_row(s, dA, (int)ld, n, dv, n);
-        potrf_lower(s, dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5);
+        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5);
         if (rhs) get_row(s, dA, (int)ld, n, dv + n, n);
     } else {
         StageScope sp(c, NMGP_STAGE_CHOL);

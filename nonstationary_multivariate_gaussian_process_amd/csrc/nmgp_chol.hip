@@ -10,7 +10,9 @@
 //     4 waves x (4x4) MFMA tiles, k-panels of 16 staged through LDS (double buffered, register prefetch).  The MFMA
 //     takes the j-side fragment as its A operand and the i-side fragment as B, so that lanes 0..15 of the result
 //     hold 16 consecutive ROWS of C: every store segment is 128 contiguous bytes of a column-major column;
-//   * k_potf2_64: one workgroup factors a 64x64 diagonal block in LDS (one barrier per column);
+//   * k_potf2_64: one workgroup factors a 64x64 diagonal block held in registers (one barrier per column, the next
+//     column is published before the rest of the current column's updates);
+//   * look-ahead: the far trailing update runs on a second stream under the next panel's latency-bound steps;
 //   * k_trsm_64: X L^T = A for 64 rows per workgroup, four lanes per row with the partial dot products combined by
 //     DPP quad permutes (no LDS round trip), rows of A kept in registers.
 //
@@ -75,16 +77,24 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
         }
     };
 
-    v4d acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
     // a wave whose 64x64 sub-tile lies strictly above the diagonal has nothing to compute
     const bool active = !(diag && wi < wj);
     const int nk = (K + SY_BK - 1) / SY_BK;
     gload(0);
+    // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
+    // the MFMA negated, so the k-loop leaves C - A A^T in registers and the epilogue is stores only.
+    // D[row = (lane>>4) + 4 reg <-> j][col = lane&15 <-> i]
+    v4d acc[4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
+                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
+                acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
+            }
     sstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     fa[t] = tA[k * SY_LD + wi * 64 + t * 16 + (lane & 15)];
-                    fb[t] = tB[k * SY_LD + wj * 64 + t * 16 + (lane & 15)];
+                    fb[t] = -tB[k * SY_LD + wj * 64 + t * 16 + (lane & 15)];
                 }
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
@@ -113,28 +123,16 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
         __syncthreads();
     }
     if (!active) return;
-    // D[row = (lane>>4) + 4 reg  <-> j][col = lane&15 <-> i].  The 16 read-modify-writes of one tj row are issued as
-    // 16 loads followed by 16 stores (a load/store/load/... sequence would serialise on memory latency).
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-        double cv[4][4];
+    for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
                 const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
-                cv[ti][r] = (i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
+                if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
             }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
-                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
-                if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = cv[ti][r] - acc[tj][ti][r];
-            }
-    }
 }
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K) {
@@ -147,54 +145,76 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
 // 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
 // info receives (goff + c + 1) for the first non-positive pivot c (LAPACK convention), left untouched otherwise.
 // ---------------------------------------------------------------------------------------------
+// reciprocal of a positive double: v_rcp_f64 seed + two Newton steps (about 1 ulp; an IEEE division costs ~3x the
+// latency and sits on the critical path of every pivot)
+__device__ __forceinline__ double fast_recip(double p) {
+    double x = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+// One pivot column of the 64x64 block.  The block is kept UNSCALED: column c holds S[r][c] as it stands when the
+// column is finalised and the update is S[r][cc] -= S[r][c] S[cc][c] / S[c][c]; the division by sqrt(pivot) is applied
+// once at the end.  Critical path per column = barrier, LDS read, reciprocal, one multiply-add for the NEXT column,
+// LDS write: the next column is published before the remaining (register-only) updates of this column are done.
 template <int KC, int GC>
-__device__ __forceinline__ void potf2_step(double (&a)[16], double (*colbuf)[64], double* __restrict__ A, int lda, int nb,
-                                  int* __restrict__ info, int goff, int r, int g, int tid) {
+__device__ __forceinline__ void potf2_step(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
+                                           int* __restrict__ info, int goff, int r, int g, int tid) {
     constexpr int c = 4 * KC + GC;
+    constexpr int NKC = (GC == 3) ? KC + 1 : KC;          // register slot / owner class of column c + 1
+    constexpr int NGC = (GC == 3) ? 0 : GC + 1;
     if (c >= nb) return;                                     // uniform
-    double* cb = colbuf[c & 1];
-    if (g == GC) cb[r] = a[KC];
-    __syncthreads();
-    // branch-free body: all broadcast reads are issued unconditionally (hipcc otherwise wraps every predicated LDS
-    // read in its own exec-mask branch with a full lgkmcnt wait: 16 serialised round trips per column)
+    const double* cb = colbuf[c & 1];
     const double piv = cb[c];
     const double mine = cb[r];
     double t[16];
 #pragma unroll
     for (int kk = KC; kk < 16; ++kk) t[kk] = cb[4 * kk + g];
-    if (!(piv > 0.0) && tid == 0) atomicCAS(info, 0, goff + c + 1);
-    const double rinv = rsqrt(piv);
-    const double lr = mine * rinv;
-    // the finished column stays in the owner's registers and is written to memory once, after the last column
-    // (a global store inside the loop would make every barrier wait for its acknowledgement)
-    {
-        const double fin = (r == c) ? (piv * rinv) : lr;
-        a[KC] = (g == GC && r >= c) ? fin : a[KC];
+    if (tid == 0) {
+        pivs[c] = piv;
+        if (!(piv > 0.0)) atomicCAS(info, 0, goff + c + 1);
+    }
+    const double pinv = fast_recip(piv);
+    const double f = mine * pinv;
+    if (c + 1 < 64) {
+        // next column first: update it, publish it, then the barrier that opens step c + 1
+        if (NKC < 16) {
+            const int cc = 4 * NKC + g;
+            const double upd = fma(-f, t[NKC < 16 ? NKC : 15], a[NKC < 16 ? NKC : 15]);
+            const bool on = (g == NGC) && (cc <= r);
+            if (NKC < 16) a[NKC < 16 ? NKC : 15] = on ? upd : a[NKC < 16 ? NKC : 15];
+            if (g == NGC) colbuf[(c + 1) & 1][r] = a[NKC < 16 ? NKC : 15];
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int kk = KC; kk < 16; ++kk) {
         const int cc = 4 * kk + g;
-        const double upd = a[kk] - lr * (t[kk] * rinv);
-        const bool on = (kk > KC || g > GC) && (cc <= r);
+        const double upd = fma(-f, t[kk], a[kk]);
+        bool on = (kk > KC || g > GC) && (cc <= r);
+        if (kk == NKC) on = on && (g != NGC);               // already done above
         a[kk] = on ? upd : a[kk];
     }
 }
 
 template <int KC>
-__device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[64], double* __restrict__ A, int lda, int nb,
-                                    int* __restrict__ info, int goff, int r, int g, int tid) {
-    potf2_step<KC, 0>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
-    potf2_step<KC, 1>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
-    potf2_step<KC, 2>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
-    potf2_step<KC, 3>(a, colbuf, A, lda, nb, info, goff, r, g, tid);
+__device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
+                                             int* __restrict__ info, int goff, int r, int g, int tid) {
+    potf2_step<KC, 0>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 1>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 2>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 3>(a, colbuf, pivs, nb, info, goff, r, g, tid);
 }
 
 __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
                                                    int goff) {
     // thread (r, g): row r = tid & 63, column class g = tid >> 6 (wave-uniform); it keeps S[r][4 kk + g], kk = 0..15,
-    // in registers.  Per column: the owning wave publishes the column through LDS (double buffered), one barrier,
-    // every thread forms the pivot's reciprocal square root and updates its registers.
+    // in registers.  Columns travel between the waves through a double-buffered LDS column.
     __shared__ double colbuf[2][64];
+    __shared__ double pivs[64];
     const int tid = threadIdx.x;
     const int r = tid & 63, g = tid >> 6;
     double a[16];
@@ -205,13 +225,18 @@ __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int ld
         if (r < nb && c <= r) v = A[(size_t)c * lda + r];
         a[kk] = v;
     }
-#define PF(K) potf2_steps4<K>(a, colbuf, A, lda, nb, info, goff, r, g, tid)
+    if (tid < 64) pivs[tid] = 1.0;
+    if (g == 0) colbuf[0][r] = a[0];
+    __syncthreads();
+#define PF(K) potf2_steps4<K>(a, colbuf, pivs, nb, info, goff, r, g, tid)
     PF(0); PF(1); PF(2); PF(3); PF(4); PF(5); PF(6); PF(7); PF(8); PF(9); PF(10); PF(11); PF(12); PF(13); PF(14); PF(15);
 #undef PF
+    __syncthreads();
+    // scale column c by 1/sqrt(pivot_c): L[r][c] = S[r][c] / sqrt(S[c][c])  (diagonal: sqrt(pivot))
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
         const int c = 4 * kk + g;
-        if (r < nb && c <= r) A[(size_t)c * lda + r] = a[kk];
+        if (r < nb && c <= r) A[(size_t)c * lda + r] = a[kk] * rsqrt(pivs[c]);
     }
 }
 
@@ -265,24 +290,32 @@ __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, i
     __shared__ double Lm[64][65];
     __shared__ double rinv[64];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx & 63, c = idx >> 6;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c <= r) v = L[(size_t)c * ldl + r];
-        Lm[r][c] = v;
-    }
-    __syncthreads();
-    if (tid < 64) rinv[tid] = 1.0 / Lm[tid][tid];
-    __syncthreads();
     const int lr = tid >> 2, g = tid & 3;
     const int row = blockIdx.x * 64 + lr;
     const bool valid = row < rows;
-    double x[16];
+    // both global fetches (this thread's row of A and its share of the factor) are issued before the first wait
+    double x[16], lv[16];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
         const int k = 4 * kk + g;
         x[kk] = (valid && k < nb) ? A[(size_t)k * lda + row] : 0.0;
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q;
+        const int r = idx & 63, c = idx >> 6;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = L[(size_t)c * ldl + r];
+        lv[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = tid + 256 * q;
+        Lm[idx & 63][idx >> 6] = lv[q];
+    }
+    __syncthreads();
+    if (tid < 64) rinv[tid] = 1.0 / Lm[tid][tid];
+    __syncthreads();
     trsm_steps4<0>(x, Lm, rinv, g);   trsm_steps4<1>(x, Lm, rinv, g);   trsm_steps4<2>(x, Lm, rinv, g);
     trsm_steps4<3>(x, Lm, rinv, g);   trsm_steps4<4>(x, Lm, rinv, g);   trsm_steps4<5>(x, Lm, rinv, g);
     trsm_steps4<6>(x, Lm, rinv, g);   trsm_steps4<7>(x, Lm, rinv, g);   trsm_steps4<8>(x, Lm, rinv, g);
@@ -317,27 +350,66 @@ void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n)
     hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256)), dim3(256), 0, s, A, lda, row, v, n);
 }
 
+static void factor_panel(hipStream_t s, double* A, int lda, int m, int c0, int w1, int* info) {
+    for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
+        const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
+        double* Ajj = A + (size_t)j0 * lda + j0;
+        potf2_64(s, Ajj, lda, jb, info, j0);
+        const int below = m - (j0 + jb);
+        if (below > 0) {
+            double* Apan = A + (size_t)j0 * lda + (j0 + jb);
+            trsm_64(s, Ajj, lda, jb, Apan, lda, below);
+            const int ncols = c0 + w1 - (j0 + jb);
+            if (ncols > 0) syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb);
+        }
+    }
+}
+
 // Blocked Cholesky of the n x n lower triangle of A with `extra` additional rows below it (rows n .. n+extra-1 of
 // the same array) that are carried through the panel solves and updates: on exit they hold  R L^-T.
-void potrf_lower(hipStream_t s, double* A, int lda, int n, int extra, int nb1, int* info) {
+//
+// Look-ahead over two streams: after panel k is factored on `s`, only the NEXT panel's columns are updated on `s`
+// (so that panel k+1 can start at once) while the rest of the trailing matrix is updated on `s2`, concurrently with
+// the latency-bound 64-wide steps of panel k+1.  ev[] must hold at least 2 * ceil(n / nb1) + 1 events; s2 == nullptr
+// (or ev == nullptr) selects the plain single-stream order.
+void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
+                 int* info) {
     const int m = n + extra;
-    for (int c0 = 0; c0 < n; c0 += nb1) {
-        const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
-        for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
-            const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
-            double* Ajj = A + (size_t)j0 * lda + j0;
-            potf2_64(s, Ajj, lda, jb, info, j0);
-            const int below = m - (j0 + jb);
-            if (below > 0) {
-                double* Apan = A + (size_t)j0 * lda + (j0 + jb);
-                trsm_64(s, Ajj, lda, jb, Apan, lda, below);
-                const int ncols = c0 + w1 - (j0 + jb);
-                if (ncols > 0) syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb);
-            }
+    const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
+    if (!la) {
+        for (int c0 = 0; c0 < n; c0 += nb1) {
+            const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
+            factor_panel(s, A, lda, m, c0, w1, info);
+            const int c1 = c0 + w1;
+            if (c1 < n)
+                syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1);
         }
+        return;
+    }
+    // everything queued on s so far (covariance build, right-hand side row) must be visible to s2
+    hipEventRecord(ev[0], s);
+    hipStreamWaitEvent(s2, ev[0], 0);
+    int k = 0;
+    bool prevB = false;
+    for (int c0 = 0; c0 < n; c0 += nb1, ++k) {
+        const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
         const int c1 = c0 + w1;
-        if (c1 < n)
-            syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1);
+        const int w1n = (c1 < n) ? ((n - c1 < nb1) ? (n - c1) : nb1) : 0;
+        const int c2 = c1 + w1n;
+        hipEvent_t evPanel = ev[1 + 2 * k], evB = ev[2 + 2 * k];
+        factor_panel(s, A, lda, m, c0, w1, info);
+        if (c1 >= n) break;
+        hipEventRecord(evPanel, s);
+        // the previous far update also wrote the next panel's columns
+        if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, w1n, w1);
+        prevB = false;
+        if (c2 < n) {
+            hipStreamWaitEvent(s2, evPanel, 0);
+            syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, m - c2, n - c2, w1);
+            hipEventRecord(evB, s2);
+            prevB = true;
+        }
     }
 }
 

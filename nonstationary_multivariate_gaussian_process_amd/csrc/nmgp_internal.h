@@ -42,6 +42,9 @@ struct StageTimer {
 struct nmgp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation
+    std::vector<hipEvent_t> chol_ev;          // events ordering the two streams
+    int chol_lookahead = 1;
     rocblas_handle blas = nullptr;
     std::string err;
 
@@ -200,6 +203,7 @@ void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff);
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows);
 void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n);
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n);
-void potrf_lower(hipStream_t s, double* A, int lda, int n, int extra, int nb1, int* info);
+void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
+                 int* info);
 
 }  // namespace nmgpk
