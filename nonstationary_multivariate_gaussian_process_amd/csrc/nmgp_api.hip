@@ -250,23 +250,26 @@ int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
     pf.alpha = alpha;
     pf.beta = beta;
     const size_t Ns = c->N;
-    NMGP_TRY(nmgp_dev_alloc(c, &pf.L, Ns * Ns));
+    pf.ld = (int)(((Ns + 15) / 16) * 16);
+    NMGP_TRY(nmgp_dev_alloc(c, &pf.L, (size_t)pf.ld * Ns));
     if (nmgp_dev_alloc(c, &pf.logdet, 1) != 0) {
         hipFree(pf.L);
         return NMGP_E_NOMEM;
     }
-    rbf_cov_sym(c->stream, c->d_x, c->N, alpha, beta, pf.L, c->N, false);
-    rocblas_status st = rocsolver_dpotrf(c->blas, rocblas_fill_lower, c->N, pf.L, c->N, c->d_info + 1);
-    half_logdet(c->stream, pf.L, c->N, c->N, pf.logdet);
+    hipMemsetAsync(c->d_info + 1, 0, sizeof(int), c->stream);
+    rbf_cov_sym(c->stream, c->d_x, c->N, alpha, beta, pf.L, pf.ld, false);
+    // RBF + 1e-6 I has condition numbers ~1e11 at N = 2048: the factorisation must be backward stable
+    // (rocSOLVER's inverse-based panel solve reports such matrices as indefinite; LAPACK and this one do not)
+    int rc = nmgp_chol_factor(c, pf.L, pf.ld, c->N, 0, c->d_info + 1);
+    half_logdet(c->stream, pf.L, pf.ld, c->N, pf.logdet);
     hipMemcpyAsync(c->h_info + 1, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (st != rocblas_status_success || e != hipSuccess || c->h_info[1] != 0) {
+    if (rc != 0 || e != hipSuccess || c->h_info[1] != 0) {
         int info = c->h_info[1];
         hipFree(pf.L);
         hipFree(pf.logdet);
-        if (st != rocblas_status_success || e != hipSuccess)
-            return nmgp_fail(c, NMGP_E_HIP, "prior factorisation failed (rocblas_status %d, %s)", (int)st,
-                             hipGetErrorString(e));
+        if (rc != 0) return rc;
+        if (e != hipSuccess) return nmgp_fail(c, NMGP_E_HIP, "prior factorisation failed (%s)", hipGetErrorString(e));
         return nmgp_fail(c, info, "GP prior covariance RBF(alpha=%g, beta=%g)+jitter is not positive definite "
                          "(leading minor %d)", alpha, beta, info);
     }
@@ -285,6 +288,16 @@ static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
         c->chol_ev.push_back(e);
     }
     return c->chol_ev.data();
+}
+
+int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
+    if (c->chol_algo == 1 && (ld % 2 == 0)) {
+        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, c->chol_nb1, d_info);
+        return 0;
+    }
+    if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
+    BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, A, ld, d_info));
+    return 0;
 }
 
 // ---- nonseparable objective --------------------------------------------------------------------
@@ -324,7 +337,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         {
             StageScope sp(c, NMGP_STAGE_CHOL);
             set_row(s, c->d_S, ld, n, c->d_y, n);                       // y rides along as row n
-            potrf_lower(s, c->stream2, chol_events(c, n), c->d_S, ld, n, 1, c->chol_nb1, c->d_info);   // row n -> L^-1 y
+            NMGP_TRY(nmgp_chol_factor(c, c->d_S, ld, n, 1, c->d_info));   // row n becomes z = L^-1 y
         }
         {
             StageScope sp(c, NMGP_STAGE_SOLVE);
@@ -362,24 +375,24 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         svc_prior_rhs(s, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
         if (pl == pL) {
             BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                      rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, N, c->d_R, N));
+                                      rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R, N));
         } else {
             BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                      rocblas_diagonal_non_unit, N, 1, &one, pl->L, N, c->d_R, N));
+                                      rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, c->d_R, N));
             BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                      rocblas_diagonal_non_unit, N, T, &one, pL->L, N, c->d_R + N, N));
+                                      rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, c->d_R + N, N));
         }
         col_sumsq(s, c->d_R, N, N, 1 + T, sc + SC_PRIORQ);
         if (want_grad && prior) {
             HIP_TRY(c, hipMemcpyAsync(c->d_R2, c->d_R, (size_t)N * (1 + T) * sizeof(double), hipMemcpyDeviceToDevice, s));
             if (pl == pL) {
                 BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                          rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, N, c->d_R2, N));
+                                          rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R2, N));
             } else {
                 BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, N, c->d_R2, N));
+                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, c->d_R2, N));
                 BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, N, c->d_R2 + N, N));
+                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, c->d_R2 + N, N));
             }
         }
     }

@@ -249,11 +249,11 @@ int prior_solve(nmgp_ctx* c, PriorFactor* pf, double* R, int ncol, double* R2) {
     const double one = 1.0;
     const int N = c->N;
     BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
     if (R2) {
         HIP_TRY(c, hipMemcpyAsync(R2, R, (size_t)N * ncol * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                  rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R2, N));
+                                  rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R2, N));
     }
     return 0;
 }
@@ -535,7 +535,7 @@ extern "C" int nmgp_mvn_logpdf_dense(nmgp_ctx* c, const double* y, const double*
     double* dr = dv + 2 * (size_t)n;
     sub_vec(s, dv, mu ? dv + n : nullptr, n, dr);
     HIP_TRY(c, hipMemsetAsync(c->d_info + 4, 0, sizeof(int), s));
-    BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, dS, n, c->d_info + 4));
+    NMGP_TRY(nmgp_chol_factor(c, dS, n, n, 0, c->d_info + 4));
     BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n, dS, n,
                               dr, 1));
     double* dres = dv + 3 * (size_t)n;
@@ -615,9 +615,9 @@ static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, d
     rbf_cov_rect(s, d_xs, S, c->d_x, N, 1, pf->alpha, pf->beta, false, Ks);
     // w = Sigma^-1 r through the cached Cholesky factor
     BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
     BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, N, R, N));
+                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
     BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, S, ncol, N, &one, Ks, N, R,
                               N, &zero, proj, S));
     return 0;
@@ -664,7 +664,7 @@ extern "C" int nmgp_predict_svc(nmgp_ctx* c, const double* pars, const double hy
     int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (P - 1), c->d_S, ld, N, M, false);
     if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, sizeof(int), s));
-    BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info));
+    NMGP_TRY(nmgp_chol_factor(c, c->d_S, ld, n, 0, c->d_info));
     HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, n, c->d_S,
                               ld, c->d_alpha, 1));

@@ -28,7 +28,8 @@ struct DevBuf {
 // for the current x (logpos.py:357,362 rebuild and re-factorise it on every evaluation).
 struct PriorFactor {
     double alpha = 0, beta = 0;
-    double* L = nullptr;       // N x N, lower, column-major
+    double* L = nullptr;       // N x N, lower, column-major, leading dimension ld
+    int ld = 0;
     double* logdet = nullptr;  // device scalar: log det of the covariance
 };
 
@@ -97,6 +98,9 @@ int nmgp_dev_alloc(nmgp_ctx* c, double** p, size_t nelem);
 int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out);
 int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out);
 int nmgp_ensure_S(nmgp_ctx* c);
+// Cholesky of the n x n lower triangle (custom gfx950 factorisation or rocSOLVER, per ctx->chol_algo); `extra` rows
+// below the matrix are carried along by the custom path only (must be 0 for rocSOLVER).
+int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info);
 struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream
     nmgp_ctx* c; int stage; hipEvent_t e0 = nullptr, e1 = nullptr;
     NmgpStage(nmgp_ctx* ctx, int st);
