@@ -46,6 +46,9 @@ def main():
                     help="chain: one N=2048 chain per GPU (headline); subjects: BASELINE config 4, independent "
                          "subjects of size --N sharded round-robin over the GPUs (8 per GPU), one stream each")
     ap.add_argument("--subjects-per-gpu", type=int, default=8)
+    ap.add_argument("--chains", type=int, default=1,
+                    help="independent MCMC chains of the subject evaluated per step through the batched entry "
+                         "(nmgp_svc_batch_*): one launch sequence covers all chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=3)
     a = ap.parse_args()
@@ -78,8 +81,21 @@ def main():
     ctx.set_data(d["x"], d["Y"])
     ctx.svc_set_pars(pars)
     want_grad = bool(a.grad)
+    B = max(1, a.chains)
+    if B > 1:
+        if want_grad:
+            raise SystemExit("--chains > 1 is the value-only batched path")
+        ctx.svc_batch_alloc(B)
+        # chain b starts from its own smooth perturbation of the generating parameters
+        ctx.svc_batch_set_pars(np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * b) for b in range(B)]))
 
     def step():
+        if B > 1:
+            ctx.svc_batch_eval(hv, True)
+            o, st = ctx.svc_batch_fetch()
+            if st.any():
+                raise RuntimeError("chain failed: %s" % st)
+            return o[0]
         ctx.svc_eval_resident(hv, True, want_grad)
         return ctx.svc_fetch(False)[0]
 
@@ -107,13 +123,13 @@ def main():
     # the reduction step of the per-subject chains (RCCL all-reduce + all-gather of 8-double rows)
     row = np.array([[rank, 1.0, a.steps] + [float(v) for v in out[:5]]])
     chain_stats, chain_table = chains.reduce_rows(row, world, world, device="cuda")
-    total_evals = a.steps * world
+    total_evals = a.steps * world * B
     value = total_evals / elapsed_max
 
     if rank == 0:
         chol_ms, chol_cnt = prof["chol"]
         chol_avg_s = (chol_ms / max(chol_cnt, 1)) * 1e-3
-        flops = n ** 3 / 3.0
+        flops = B * n ** 3 / 3.0
         achieved = flops / chol_avg_s / 1e12 if chol_avg_s > 0 else 0.0
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1] > 0}
         cov_ms = stage_ms.get("cov", 0.0)
@@ -129,8 +145,9 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed_max / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "nonseparable GP nlogpos_obj_SVC %s, D=%d, N=%d (MN=%d), one chain per GPU"
-                                   % ("value+gradient" if want_grad else "value", M, N, n),
+            "config": {"workload": "nonseparable GP nlogpos_obj_SVC %s, D=%d, N=%d (MN=%d), %d independent chain(s) per "
+                                   "GPU evaluated per step" % ("value+gradient" if want_grad else "value", M, N, n, B),
+                       "chains_per_gpu": B,
                        "stage_ms": stage_ms, "neglog_rank0": float(out[0]),
                        "chains_ok": int(chain_stats[0]), "sum_neglog_all_chains": float(chain_stats[3]),
                        "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,

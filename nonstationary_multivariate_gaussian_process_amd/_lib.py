@@ -39,6 +39,11 @@ SIGNATURES = {
     "nmgp_svc_grad_dev": (V, [V]),
     "nmgp_svc_eval_resident": (I, [V, P, I, I]),
     "nmgp_svc_fetch": (I, [V, P, P]),
+    "nmgp_svc_batch_alloc": (I, [V, I]),
+    "nmgp_svc_batch_set_pars": (I, [V, P]),
+    "nmgp_svc_batch_pars_dev": (V, [V]),
+    "nmgp_svc_batch_eval": (I, [V, P, I]),
+    "nmgp_svc_batch_fetch": (I, [V, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_covariance": (I, [V, P, P]),
     "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
     "nmgp_logpos_sta": (I, [V, P, P, I, P, P]),
@@ -196,6 +201,29 @@ class Context:
         grad = np.empty(self.N * (1 + self.T) + 1) if want_grad else None
         self.check(self.lib.nmgp_svc_fetch(self.h, ptr(out), ptr(grad)))
         return out, grad
+
+    # -- batched chains ---------------------------------------------------------------------------
+    def svc_batch_alloc(self, B):
+        self.check(self.lib.nmgp_svc_batch_alloc(self.h, int(B)))
+        self.B = int(B)
+
+    def svc_batch_set_pars(self, pars):
+        pars = as_f64(pars)
+        P_ = self.N * (1 + self.T) + 1
+        if pars.shape != (self.B, P_):
+            raise NmgpError("batched parameters must be [B=%d, P=%d], got %s" % (self.B, P_, pars.shape))
+        self.check(self.lib.nmgp_svc_batch_set_pars(self.h, ptr(pars)))
+        self.sync()
+
+    def svc_batch_eval(self, hyper, prior=True):
+        hyper = as_f64(hyper)
+        self.check(self.lib.nmgp_svc_batch_eval(self.h, ptr(hyper), int(bool(prior))))
+
+    def svc_batch_fetch(self):
+        out = np.empty((self.B, 5))
+        status = np.zeros(self.B, dtype=np.int32)
+        self.check(self.lib.nmgp_svc_batch_fetch(self.h, ptr(out), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out, status
 
     def svc_covariance(self, pars):
         pars = as_f64(pars).reshape(-1)

@@ -107,6 +107,16 @@ static void free_subject(nmgp_ctx* c) {
     }
     c->S_cap = c->K_cap = c->part_cap = 0;
     free_priors(c);
+    {
+        double** bp[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q};
+        for (double** p : bp) {
+            if (*p) hipFree(*p);
+            *p = nullptr;
+        }
+        if (c->b_info) hipFree(c->b_info);
+        c->b_info = nullptr;
+        c->batch = 0;
+    }
 }
 
 // ---- context -----------------------------------------------------------------------------------
@@ -292,7 +302,7 @@ static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
 
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
     if (c->chol_algo == 1 && (ld % 2 == 0)) {
-        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, c->chol_nb1, d_info);
+        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, c->chol_nb1, d_info, 1, 0, 0);
         return 0;
     }
     if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
@@ -336,12 +346,12 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     if (c->chol_algo == 1) {
         {
             StageScope sp(c, NMGP_STAGE_CHOL);
-            set_row(s, c->d_S, ld, n, c->d_y, n);                       // y rides along as row n
+            set_row(s, c->d_S, ld, n, c->d_y, n, 1, 0, 0);              // y rides along as row n
             NMGP_TRY(nmgp_chol_factor(c, c->d_S, ld, n, 1, c->d_info));   // row n becomes z = L^-1 y
         }
         {
             StageScope sp(c, NMGP_STAGE_SOLVE);
-            get_row(s, c->d_S, ld, n, c->d_z, n);
+            get_row(s, c->d_S, ld, n, c->d_z, n, 1, 0, 0);
             if (want_grad) {
                 HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
                 BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
@@ -470,6 +480,145 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
     return nmgp_svc_fetch(c, out5, grad);
 }
 
+// ---- batched evaluation: B chains of the resident subject per launch sequence --------------------------
+// MCMC runs many independent chains per subject; their factorisations have identical shapes, so every kernel of
+// the forward path takes the chain index as a grid dimension.  The 96 latency-bound 64-wide panel steps of the
+// Cholesky are then paid once per batch instead of once per chain, and the MFMA trailing updates fill the chip.
+static void free_batch(nmgp_ctx* c) {
+    double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q};
+    for (double** p : ptrs) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    if (c->b_info) hipFree(c->b_info);
+    c->b_info = nullptr;
+    c->batch = 0;
+}
+
+extern "C" int nmgp_svc_batch_alloc(nmgp_ctx* c, int B) {
+    if (!c) return NMGP_E_NULL;
+    if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called first");
+    if (B <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "batch size must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_batch(c);
+    const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc;
+    const size_t ld = ((n + 1 + 15) / 16) * 16;
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_pars, (size_t)B * P));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_ell, (size_t)B * N));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_Lv, (size_t)B * N * T));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_S, (size_t)B * ld * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_z, (size_t)B * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_R, N * (size_t)B * (1 + T)));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_scal, (size_t)B * 16));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_q, (size_t)B * (1 + T)));
+    HIP_TRY(c, hipMalloc((void**)&c->b_info, (size_t)B * sizeof(int)));
+    HIP_TRY(c, hipMemsetAsync(c->b_pars, 0, (size_t)B * P * sizeof(double), c->stream));
+    c->batch = B;
+    return 0;
+}
+
+extern "C" int nmgp_svc_batch_set_pars(nmgp_ctx* c, const double* pars) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars) return nmgp_fail(c, NMGP_E_NULL, "pars must not be NULL");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->b_pars, pars, (size_t)c->batch * c->P_svc * sizeof(double), hipMemcpyHostToDevice,
+                              c->stream));
+    return 0;
+}
+
+extern "C" double* nmgp_svc_batch_pars_dev(nmgp_ctx* c) { return c ? c->b_pars : nullptr; }
+
+extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper) return nmgp_fail(c, NMGP_E_NULL, "hyper must not be NULL");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T, n = c->n, B = c->batch;
+    const long long P = c->P_svc;
+    const int ld = (int)((((size_t)n + 1 + 15) / 16) * 16);
+    const long long bs = (long long)ld * n;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
+    const double a = hyper[6], b = hyper[7];
+    hipStream_t s = c->stream;
+    PriorFactor *pl = nullptr, *pL = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    HIP_TRY(c, hipMemsetAsync(c->b_info, 0, (size_t)B * sizeof(int), s));
+    {
+        StageScope sp(c, NMGP_STAGE_COV);
+        svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
+        int r = svc_cov_build(s, c->d_x, c->b_ell, c->b_Lv, c->b_pars + (P - 1), c->b_S, ld, N, M, false, B, bs);
+        if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_CHOL);
+        set_row(s, c->b_S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
+        potrf_lower(s, c->stream2, chol_events(c, n), c->b_S, ld, n, 1, c->chol_nb1, c->b_info, B, bs, 1);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_SOLVE);
+        get_row(s, c->b_S, ld, n, c->b_z, n, B, bs, n);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_REDUCE);
+        chol_logdet_quad(s, c->b_S, ld, n, c->b_z, c->b_scal, c->b_scal + 1, B, bs, 16);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_PRIOR);
+        const double one = 1.0;
+        svc_prior_rhs(s, c->b_pars, N, T, mu_l, mu_L, c->b_R, N, B);
+        if (pl == pL) {
+            // one multi-right-hand-side solve for the whole batch: the prior factor depends on (x, alpha, beta) only
+            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                      rocblas_diagonal_non_unit, N, B * (1 + T), &one, pl->L, pl->ld, c->b_R, N));
+        } else {
+            for (int z = 0; z < B; ++z) {
+                double* Rz = c->b_R + (size_t)z * (1 + T) * N;
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, Rz, N));
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, Rz + N, N));
+            }
+        }
+        col_sumsq(s, c->b_R, N, N, B * (1 + T), c->b_q);
+    }
+    {
+        StageScope sp(c, NMGP_STAGE_REDUCE);
+        const double ig_const = a * std::log(b) - std::lgamma(a);
+        svc_finalize(s, c->b_scal, c->b_scal + 1, c->b_q, pl->logdet, pL->logdet, c->b_pars, P, N, T, a, b, ig_const,
+                     prior, c->b_scal + 8, B, 16);
+    }
+    c->last_kind = 2;
+    return 0;
+}
+
+// out: [B, 5] verbose tuples; status: [B] (0 ok, k > 0 leading minor k not positive definite, NMGP_NUM_NAN).
+// A failing chain does not fail the call: the return value is 0 and its status / NaN row tell.
+extern "C" int nmgp_svc_batch_fetch(nmgp_ctx* c, double* out, int* status) {
+    if (!c) return NMGP_E_NULL;
+    if (!out) return nmgp_fail(c, NMGP_E_NULL, "out must not be NULL");
+    if (c->last_kind != 2) return nmgp_fail(c, NMGP_E_STATE, "no batched evaluation is pending");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int B = c->batch;
+    std::vector<double> h((size_t)B * 16);
+    std::vector<int> hi(B);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), c->b_info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int z = 0; z < B; ++z) {
+        int st = hi[z];
+        for (int k = 0; k < 5; ++k) out[(size_t)z * 5 + k] = h[(size_t)z * 16 + 8 + k];
+        if (st == 0 && (!std::isfinite(out[(size_t)z * 5]) || !std::isfinite(out[(size_t)z * 5 + 1]))) st = NMGP_NUM_NAN;
+        if (st != 0)
+            for (int k = 0; k < 5; ++k) out[(size_t)z * 5 + k] = std::nan("");
+        if (status) status[z] = st;
+    }
+    return 0;
+}
+
 extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out) {
     if (!c) return NMGP_E_NULL;
     if (!out) return nmgp_fail(c, NMGP_E_NULL, "out must not be NULL");
@@ -507,9 +656,9 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     HIP_TRY(c, hipMemsetAsync(c->d_info + 5, 0, sizeof(int), s));
     if (algo == 1) {
         StageScope sp(c, NMGP_STAGE_CHOL);
-        if (rhs) set_row(s, dA, (int)ld, n, dv, n);
-        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5);
-        if (rhs) get_row(s, dA, (int)ld, n, dv + n, n);
+        if (rhs) set_row(s, dA, (int)ld, n, dv, n, 1, 0, 0);
+        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
+        if (rhs) get_row(s, dA, (int)ld, n, dv + n, n, 1, 0, 0);
     } else {
         StageScope sp(c, NMGP_STAGE_CHOL);
         BLAS_TRY(c, rocsolver_dpotrf(c->blas, rocblas_fill_lower, n, dA, (int)ld, c->d_info + 5));

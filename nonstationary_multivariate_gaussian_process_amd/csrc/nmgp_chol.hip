@@ -42,11 +42,13 @@ __device__ inline double2 load2_guard(const double* __restrict__ p, int r, int r
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
 __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C,
-                                                        int ldc, int mrows, int ncols, int K) {
+                                                        int ldc, int mrows, int ncols, int K, long long bstride) {
     __shared__ double sA[2][SY_BK * SY_LD];
     __shared__ double sB[2][SY_BK * SY_LD];
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (bi < bj) return;
+    A += (size_t)blockIdx.z * bstride;       // batch of independent matrices (one per chain), same shape
+    C += (size_t)blockIdx.z * bstride;
     const bool diag = (bi == bj);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
@@ -135,10 +137,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
             }
 }
 
-void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K) {
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
+                long long bstride) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
-    dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM));
-    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K);
+    dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
+    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,7 +213,9 @@ __device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[6
 }
 
 __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
-                                                   int goff) {
+                                                   int goff, long long bstride, int istride) {
+    A += (size_t)blockIdx.x * bstride;
+    info += (size_t)blockIdx.x * istride;
     // thread (r, g): row r = tid & 63, column class g = tid >> 6 (wave-uniform); it keeps S[r][4 kk + g], kk = 0..15,
     // in registers.  Columns travel between the waves through a double-buffered LDS column.
     __shared__ double colbuf[2][64];
@@ -240,8 +245,9 @@ __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int ld
     }
 }
 
-void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff) {
-    hipLaunchKernelGGL(k_potf2_64, dim3(1), dim3(256), 0, s, A, lda, nb, info, goff);
+void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
+              int istride) {
+    hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +292,9 @@ __device__ __forceinline__ void trsm_steps4(double (&x)[16], const double (*Lm)[
 }
 
 __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, int ldl, int nb, double* __restrict__ A,
-                                                  int lda, int rows) {
+                                                  int lda, int rows, long long bstride) {
+    L += (size_t)blockIdx.y * bstride;
+    A += (size_t)blockIdx.y * bstride;
     __shared__ double Lm[64][65];
     __shared__ double rinv[64];
     const int tid = threadIdx.x;
@@ -329,38 +337,46 @@ __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, i
     }
 }
 
-void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows) {
+void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
+             long long bstride) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64)), dim3(256), 0, s, L, ldl, nb, A, lda, rows);
+    hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
 }
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
-__global__ void k_set_row(double* __restrict__ A, int lda, int row, const double* __restrict__ v, int n) {
+// vstride = 0 broadcasts one vector to every matrix of the batch (all chains of a subject share y)
+__global__ void k_set_row(double* __restrict__ A, int lda, int row, const double* __restrict__ v, int n,
+                          long long bstride, long long vstride) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) A[(size_t)j * lda + row] = v[j];
+    if (j < n) A[(size_t)blockIdx.y * bstride + (size_t)j * lda + row] = v[(size_t)blockIdx.y * vstride + j];
 }
-void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n) {
-    hipLaunchKernelGGL(k_set_row, dim3(cdiv_c(n, 256)), dim3(256), 0, s, A, lda, row, v, n);
+void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n, int batch, long long bstride,
+             long long vstride) {
+    hipLaunchKernelGGL(k_set_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
 }
-__global__ void k_get_row(const double* __restrict__ A, int lda, int row, double* __restrict__ v, int n) {
+__global__ void k_get_row(const double* __restrict__ A, int lda, int row, double* __restrict__ v, int n,
+                          long long bstride, long long vstride) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) v[j] = A[(size_t)j * lda + row];
+    if (j < n) v[(size_t)blockIdx.y * vstride + j] = A[(size_t)blockIdx.y * bstride + (size_t)j * lda + row];
 }
-void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n) {
-    hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256)), dim3(256), 0, s, A, lda, row, v, n);
+void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
+             long long vstride) {
+    hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
 }
 
-static void factor_panel(hipStream_t s, double* A, int lda, int m, int c0, int w1, int* info) {
+static void factor_panel(hipStream_t s, double* A, int lda, int m, int c0, int w1, int* info, int batch,
+                         long long bs, int is) {
     for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
         const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
         double* Ajj = A + (size_t)j0 * lda + j0;
-        potf2_64(s, Ajj, lda, jb, info, j0);
+        potf2_64(s, Ajj, lda, jb, info, j0, batch, bs, is);
         const int below = m - (j0 + jb);
         if (below > 0) {
             double* Apan = A + (size_t)j0 * lda + (j0 + jb);
-            trsm_64(s, Ajj, lda, jb, Apan, lda, below);
+            trsm_64(s, Ajj, lda, jb, Apan, lda, below, batch, bs);
             const int ncols = c0 + w1 - (j0 + jb);
-            if (ncols > 0) syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb);
+            if (ncols > 0)
+                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs);
         }
     }
 }
@@ -372,17 +388,22 @@ static void factor_panel(hipStream_t s, double* A, int lda, int m, int c0, int w
 // (so that panel k+1 can start at once) while the rest of the trailing matrix is updated on `s2`, concurrently with
 // the latency-bound 64-wide steps of panel k+1.  ev[] must hold at least 2 * ceil(n / nb1) + 1 events; s2 == nullptr
 // (or ev == nullptr) selects the plain single-stream order.
+// batch > 1 factors `batch` matrices of identical shape at once (matrix b at A + b * bstride, status word at
+// info + b * istride): every launch covers all of them, so the latency of the 64-wide steps is paid once per batch.
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
-                 int* info) {
+                 int* info, int batch, long long bstride, int istride) {
+    const int is = istride;
+    const long long bs = bstride;
     const int m = n + extra;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
     if (!la) {
         for (int c0 = 0; c0 < n; c0 += nb1) {
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
-            factor_panel(s, A, lda, m, c0, w1, info);
+            factor_panel(s, A, lda, m, c0, w1, info, batch, bs, is);
             const int c1 = c0 + w1;
             if (c1 < n)
-                syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1);
+                syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1, batch,
+                           bs);
         }
         return;
     }
@@ -397,16 +418,16 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         const int w1n = (c1 < n) ? ((n - c1 < nb1) ? (n - c1) : nb1) : 0;
         const int c2 = c1 + w1n;
         hipEvent_t evPanel = ev[1 + 2 * k], evB = ev[2 + 2 * k];
-        factor_panel(s, A, lda, m, c0, w1, info);
+        factor_panel(s, A, lda, m, c0, w1, info, batch, bs, is);
         if (c1 >= n) break;
         hipEventRecord(evPanel, s);
         // the previous far update also wrote the next panel's columns
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
-        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, w1n, w1);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, w1n, w1, batch, bs);
         prevB = false;
         if (c2 < n) {
             hipStreamWaitEvent(s2, evPanel, 0);
-            syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, m - c2, n - c2, w1);
+            syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, m - c2, n - c2, w1, batch, bs);
             hipEventRecord(evB, s2);
             prevB = true;
         }

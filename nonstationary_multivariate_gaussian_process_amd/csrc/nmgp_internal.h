@@ -83,6 +83,17 @@ struct nmgp_ctx {
     size_t K_cap = 0;
     double* d_w = nullptr;      // [N] eigenvalues of K_x
     double* d_E = nullptr;      // [N] syevd workspace
+    // batched value-only evaluation: B chains of the resident subject, one launch sequence for all of them
+    int batch = 0;
+    double* b_pars = nullptr;   // [B, P]
+    double* b_ell = nullptr;    // [B, N]
+    double* b_Lv = nullptr;     // [B, N, T]
+    double* b_S = nullptr;      // [B] x (ld x n) covariance / factor buffers
+    double* b_z = nullptr;      // [B, n]
+    double* b_R = nullptr;      // [N, B (1 + T)]
+    double* b_scal = nullptr;   // [B, 16] : logdet, quad, out5...
+    double* b_q = nullptr;      // [B (1 + T)]
+    int* b_info = nullptr;      // [B]
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
 
@@ -133,10 +144,10 @@ struct NmgpStage {   // RAII HIP-event timer of one stage on the context's strea
 namespace nmgpk {
 
 // parameter unpacking: ell = exp(tilde_l), Lv = tril factors with exp on the diagonal slots
-void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv);
+void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv, int batch = 1);
 // kernel #1: fused nonseparable covariance (lower triangle, column-major, output-major indices)
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                  double* S, int ld, int N, int M, bool full);
+                  double* S, int ld, int N, int M, bool full, int batch = 1, long long sstride = 0);
 // symmetric N x N builds (lower triangle unless full)
 void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full);
 void gibbs_cov_sym(hipStream_t s, const double* x, const double* sig, const double* ell, int N, double* out, int ld,
@@ -150,12 +161,13 @@ void gibbs_cov_rect(hipStream_t s, const double* x1, const double* s1, const dou
 void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* b, int br, int bc, double* out);
 // reductions
 void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
-                      double* out_quad);
+                      double* out_quad, int batch = 1, long long bstride = 0, int ostride = 0);
 void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out);
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out);
 void fill_lower_to_full(hipStream_t s, double* A, int ld, int n);
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
-void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld);
+void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
+                   int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part);
@@ -164,7 +176,7 @@ void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, con
                     int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad);
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5);
+                  double ig_const, int prior, double* out5, int batch = 1, int sstride = 0);
 void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out);
 // ---- nmgp_kernels_eig.hip ----
 int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, const double* B, int m1, int m2,
@@ -202,12 +214,17 @@ void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_
               double* kss);
 void add_diag(hipStream_t s, double* A, int ld, int n, double v);
 // ---- nmgp_chol.hip ----
-void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K);
-void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff);
-void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows);
-void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n);
-void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n);
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
+                long long bstride);
+void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
+              int istride);
+void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
+             long long bstride);
+void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n, int batch, long long bstride,
+             long long vstride);
+void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
+             long long vstride);
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
-                 int* info);
+                 int* info, int batch, long long bstride, int istride);
 
 }  // namespace nmgpk

@@ -39,6 +39,10 @@ __global__ void k_svc_prep(const double* __restrict__ pars, int N, int M, int T,
                            double* __restrict__ Lv) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    // blockIdx.y = chain of the batch: parameter vectors are stacked [B, P], the unpacked curves [B, N] / [B, N, T]
+    pars += (size_t)blockIdx.y * ((size_t)N * (1 + T) + 1);
+    ell += (size_t)blockIdx.y * N;
+    Lv += (size_t)blockIdx.y * N * T;
     ell[i] = exp(pars[i]);
     const double* u = pars + N + (size_t)i * T;
     double* o = Lv + (size_t)i * T;
@@ -47,9 +51,9 @@ __global__ void k_svc_prep(const double* __restrict__ pars, int N, int M, int T,
         for (int c = 0; c <= r; ++c, ++t) o[t] = (c == r) ? exp(u[t]) : u[t];
 }
 
-void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv) {
+void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv, int batch) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_prep, dim3(cdiv(N, 256)), dim3(256), 0, s, pars, N, M, T, ell, Lv);
+    hipLaunchKernelGGL(k_svc_prep, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, M, T, ell, Lv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -65,12 +69,17 @@ void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, doub
 template <int M, bool FULL>
 __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, const double* __restrict__ ell,
                                                   const double* __restrict__ Lv, const double* __restrict__ tse,
-                                                  double* __restrict__ S, int ld, int N) {
+                                                  double* __restrict__ S, int ld, int N, long long sstride) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T];
     const int I = blockIdx.x, J = blockIdx.y;
     if (!FULL && M == 1 && I < J) return;
+    // blockIdx.z = chain of the batch (same x for all chains, one covariance buffer per chain)
+    ell += (size_t)blockIdx.z * N;
+    Lv += (size_t)blockIdx.z * N * T;
+    tse += (size_t)blockIdx.z * ((size_t)N * (1 + T) + 1);
+    S += (size_t)blockIdx.z * sstride;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j0 = J * TJ;
     if (tid < TJ) {
@@ -124,25 +133,25 @@ __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, c
 
 template <int M>
 static void launch_svc_cov(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                           double* S, int ld, int N, bool full) {
-    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+                           double* S, int ld, int N, bool full, int batch, long long sstride) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
-        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N);
+        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride);
     else
-        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N);
+        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride);
 }
 
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse, double* S,
-                  int ld, int N, int M, bool full) {
+                  int ld, int N, int M, bool full, int batch, long long sstride) {
     switch (M) {
-        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full); break;
-        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full); break;
+        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
         default: return NMGP_E_UNSUPPORTED;
     }
     return 0;
@@ -291,8 +300,14 @@ void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_logdet_quad(const double* __restrict__ L, int ld, int n,
                                                        const double* __restrict__ z, double* __restrict__ out_logdet,
-                                                       double* __restrict__ out_quad) {
+                                                       double* __restrict__ out_quad, long long bstride,
+                                                       int ostride) {
     __shared__ double sh[16];
+    // blockIdx.x = matrix of the batch
+    L += (size_t)blockIdx.x * bstride;
+    if (z) z += (size_t)blockIdx.x * n;
+    out_logdet += (size_t)blockIdx.x * ostride;
+    if (out_quad) out_quad += (size_t)blockIdx.x * ostride;
     double a = 0.0, q = 0.0;
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         a += log(L[(size_t)r * ld + r]);
@@ -310,13 +325,14 @@ __global__ __launch_bounds__(1024) void k_logdet_quad(const double* __restrict__
 }
 
 void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
-                      double* out_quad) {
-    hipLaunchKernelGGL(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, z, out_logdet, out_quad);
+                      double* out_quad, int batch, long long bstride, int ostride) {
+    hipLaunchKernelGGL(k_logdet_quad, dim3(batch), dim3(1024), 0, s, L, ld, n, z, out_logdet, out_quad, bstride,
+                       ostride);
 }
 
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out) {
     hipLaunchKernelGGL(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, (const double*)nullptr, out,
-                       (double*)nullptr);
+                       (double*)nullptr, 0LL, 0);
 }
 
 // out[c] = sum_r R[r, c]^2 (one workgroup per column)
@@ -374,12 +390,16 @@ __global__ void k_svc_prior_rhs(const double* __restrict__ pars, int N, int T, d
                                 double* __restrict__ R, int ld) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    // blockIdx.y = chain: its 1 + T columns follow those of the previous chain (one multi-RHS solve for the batch)
+    pars += (size_t)blockIdx.y * ((size_t)N * (1 + T) + 1);
+    R += (size_t)blockIdx.y * (1 + T) * ld;
     R[i] = pars[i] - mu_l;
     for (int t = 0; t < T; ++t) R[(size_t)(1 + t) * ld + i] = pars[N + (size_t)i * T + t] - mu_L;
 }
 
-void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld) {
-    hipLaunchKernelGGL(k_svc_prior_rhs, dim3(cdiv(N, 256)), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
+void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
+                   int batch) {
+    hipLaunchKernelGGL(k_svc_prior_rhs, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
 }
 
 // HBM stream micro-benchmark (16 B per lane)
@@ -583,8 +603,15 @@ void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, con
 __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* __restrict__ quad,
                                const double* __restrict__ q, const double* __restrict__ hl_l,
                                const double* __restrict__ hl_L, const double* __restrict__ pars, long long P, int N,
-                               int T, double a, double b, double ig_const, int prior, double* __restrict__ out5) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                               int T, double a, double b, double ig_const, int prior, double* __restrict__ out5,
+                               int sstride) {
+    if (threadIdx.x != 0) return;
+    // blockIdx.x = chain: scalar blocks are sstride apart, prior terms 1 + T apart, parameter vectors P apart
+    logdet += (size_t)blockIdx.x * sstride;
+    quad += (size_t)blockIdx.x * sstride;
+    out5 += (size_t)blockIdx.x * sstride;
+    q += (size_t)blockIdx.x * (1 + T);
+    pars += (size_t)blockIdx.x * P;
     const double LOG2PI = 1.8378770664093453;
     const double tse = pars[P - 1];
     const double sigma2 = exp(tse);
@@ -610,9 +637,9 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
 
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5) {
-    hipLaunchKernelGGL(k_svc_finalize, dim3(1), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
-                       ig_const, prior, out5);
+                  double ig_const, int prior, double* out5, int batch, int sstride) {
+    hipLaunchKernelGGL(k_svc_finalize, dim3(batch), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
+                       ig_const, prior, out5, sstride);
 }
 
 // half log-determinant of a Cholesky factor: sum log L_rr

@@ -362,3 +362,32 @@ def test_rocsolver_and_custom_factorisation_agree_on_the_objective():
     assert relerr(res["custom"][0], res["rocsolver"][0]) < VAL_TOL
     assert vec_relerr(res["custom"][1], res["rocsolver"][1]) < GRAD_TOL
     assert relerr(res["custom"][0], g["out"]) < VAL_TOL and relerr(res["rocsolver"][0], g["out"]) < VAL_TOL
+
+
+def test_batched_chains_match_single_evaluations(ctx):
+    """B chains per launch sequence: every row equals the single-chain evaluation; a broken chain is isolated."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    for name, B in (("svc_rngfree_N64_M3", 5), ("svc_sim_N1024_M3_base", 3), ("svc_sim_N77_M2_base", 4)):
+        g = golden(name)
+        ctx.set_data(g["x"], g["Y"])
+        ctx.svc_batch_alloc(B)
+        pars = np.stack([sim.perturb(g["pars"], 0.02 * k, 0.3 * k) for k in range(B)])
+        pars[0] = g["pars"]
+        ctx.svc_batch_set_pars(pars)
+        ctx.svc_batch_eval(g["hyper"], True)
+        out, status = ctx.svc_batch_fetch()
+        assert np.all(status == 0)
+        assert relerr(out[0], g["out"]) < VAL_TOL and relerr(out[0][1], g["out"][1]) < LIK_TOL
+        for k in range(B):
+            single, _ = ctx.logpos_svc(pars[k], g["hyper"], prior=True)
+            assert relerr(out[k][1], single[1]) < 1e-12 and relerr(out[k], single) < 1e-9, (name, k, out[k], single)
+    g = golden("svc_rngfree_N64_M3")
+    ctx.set_data(g["x"], g["Y"])
+    ctx.svc_batch_alloc(3)
+    pars = np.stack([g["pars"]] * 3)
+    pars[1, 5] = np.nan
+    ctx.svc_batch_set_pars(pars)
+    ctx.svc_batch_eval(g["hyper"], True)
+    out, status = ctx.svc_batch_fetch()
+    assert status[0] == 0 and status[2] == 0 and status[1] != 0
+    assert np.all(np.isnan(out[1])) and relerr(out[0], g["out"]) < VAL_TOL and np.array_equal(out[0], out[2])
