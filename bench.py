@@ -4,12 +4,16 @@ MN = 6144) on MI355X -- BASELINE.json's metric on its configs[2].
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is ONE evaluation of ``nlogpos_obj_SVC`` (value; ``--grad`` adds the gradient) on synthetic data of the
-reference simulator's recipe (SIM_code/sim.py:177-263), with the subject's data and the parameter vector already
-resident in HBM when the timed region starts; the host reads back the 5 verbose scalars after every step as an MCMC
-chain would.  With N GPUs every rank runs an independent chain on its own subject (the reference's one-rank-per-
-subject pattern, Nonseparable_model_mpisim.py:305-306): weak scaling, no collective on the data path; RCCL is used
-for the barrier, the max-over-ranks time and the final reduction of the chains' statistics only.
+A "step" is one pass of the hot path over one batch of synthetic input: ONE evaluation of ``nlogpos_obj_SVC`` for each
+of ``--chains`` (default 16) independent MCMC chains of the rank's subject -- the chains are the reference's
+embarrassingly-parallel unit (it runs them as separate processes, Nonseparable_model_mpisim.py:305-306); here their
+parameter vectors are stacked [B, P] in HBM and one launch sequence evaluates all of them (nmgp_svc_batch_*), which is
+what amortises the latency-bound panel steps of the Cholesky.  ``value`` counts evaluations: steps x chains x GPUs /
+time.  ``--chains 1`` gives the single-chain latency path (``--grad`` adds the gradient there).  Data follow the
+reference simulator's recipe (SIM_code/sim.py:177-263); the subject's data and all parameter vectors are resident in
+HBM when the timed region starts, and the host reads back the verbose scalars of every chain after every step as an
+MCMC driver would.  With N GPUs every rank owns its own subject and chains: weak scaling, no collective on the data
+path; RCCL is used for the barrier, the max-over-ranks time and the final reduction of the chains' statistics only.
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
   roofline      -- the dominant kernel (the FP64 Cholesky factorisation of the 6144^2 covariance): algorithmic
@@ -32,6 +36,9 @@ if ROOT not in sys.path:
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (vendor dense figure).  The CDNA4 guide lists no
                                    # FP64 row; the measured rocBLAS dgemm rate is reported beside it in `config`.
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per batched factorisation from the rocprofv3 PMC passes (profiles/, filled in by hand from the committed
+# counter CSVs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None until measured.
+TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def main():
@@ -46,7 +53,7 @@ def main():
                     help="chain: one N=2048 chain per GPU (headline); subjects: BASELINE config 4, independent "
                          "subjects of size --N sharded round-robin over the GPUs (8 per GPU), one stream each")
     ap.add_argument("--subjects-per-gpu", type=int, default=8)
-    ap.add_argument("--chains", type=int, default=1,
+    ap.add_argument("--chains", type=int, default=16,
                     help="independent MCMC chains of the subject evaluated per step through the batched entry "
                          "(nmgp_svc_batch_*): one launch sequence covers all chains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,7 +140,7 @@ def main():
         achieved = flops / chol_avg_s / 1e12 if chol_avg_s > 0 else 0.0
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1] > 0}
         cov_ms = stage_ms.get("cov", 0.0)
-        cov_bytes = 8.0 * n * (n + 1) / 2.0
+        cov_bytes = B * 8.0 * n * (n + 1) / 2.0
         try:
             dgemm_tf = ctx.measure_dgemm_tflops(4096, 5)
             hbm_gbs = ctx.measure_hbm_gbs(1 << 30, 10)
@@ -152,9 +159,11 @@ def main():
                        "chains_ok": int(chain_stats[0]), "sum_neglog_all_chains": float(chain_stats[3]),
                        "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,
                        "cov_build_gbs": (cov_bytes / (cov_ms * 1e-3) / 1e9) if cov_ms > 0 else None},
-            "roofline": {"kernel": "FP64 Cholesky of the %dx%d covariance (rocSOLVER dpotrf stage)" % (n, n),
+            "roofline": {"kernel": "blocked FP64 Cholesky of %d %dx%d covariances per launch sequence: k_syrk_lower "
+                                   "(v_mfma_f64_16x16x4_f64 trailing updates) + k_potf2_64 / k_trsm_64 panel steps; "
+                                   "algorithmic flop = chains * n^3/3, time = HIP events around the stage" % (B, n, n),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None},
+                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": TRAFFIC_BYTES_PER_LAUNCH},
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(d, pars, hyper, a.cpu_evals, want_grad)
