@@ -38,7 +38,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (vendor dense figure; SU
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per batched factorisation from the rocprofv3 PMC passes (profiles/, filled in by hand from the committed
 # counter CSVs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = None
+TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 16): 8.915e10}    # profiles/r01_v2_batched16_pmc_traffic.json
 
 
 def main():
@@ -163,7 +163,8 @@ def main():
                                    "(v_mfma_f64_16x16x4_f64 trailing updates) + k_potf2_64 / k_trsm_64 panel steps; "
                                    "algorithmic flop = chains * n^3/3, time = HIP events around the stage" % (B, n, n),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": TRAFFIC_BYTES_PER_LAUNCH},
+                         "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((N, M, B))},
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(d, pars, hyper, a.cpu_evals, want_grad)
