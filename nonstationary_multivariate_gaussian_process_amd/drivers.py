@@ -1,0 +1,163 @@
+"""The loops the log-posterior path is called from: MAP by Adam and HMC.
+
+* :func:`map_nonseparable` mirrors ``train()`` of ``Nonseparable_Model/Nonseparable_model.py:147-210``: Adam over the
+  three leaves ``[tilde_l | uL_vecs | tilde_sigma2_err]`` (lr 0.2 each), ``NegLog.backward()`` per iteration,
+  ``target_value_hist[i] = -NegLog``, and the flat parameter vector pickled as ``MAP.dat`` every 100 iterations.
+* :class:`HMCSampler` replaces the reference's EXTERNAL, un-vendored ``HMC_Sampler.HMC_sampler.sampler`` (a sibling
+  checkout that is not in the reference tree; call sites ``Nonseparable_model.py:228-231``): same constructor keywords
+  as those call sites (``sample_size, potential_func, init_position, step_size, num_steps_in_leap, adaptive_step_size,
+  M, duplicate_samples, TensorType, **potential kwargs``) and ``main_hmc_loop() -> (samples [S, P], info)``.  Its
+  trajectories cannot be pinned against the reference (the package is absent): it is validated by energy conservation
+  and by posterior moments on a Gaussian target (tests/test_drivers.py).
+
+Host-side orchestration only; every evaluation of the potential goes to the GPU through ``Utility.logpos``.
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+import torch
+
+from .Utility import logpos, settings
+
+
+def map_nonseparable(x, Y, pars0, hyper_pars, N_opt=1000, lr=2e-1, checkpoint_path=None, checkpoint_every=100,
+                     verbose=False, callback=None):
+    """MAP estimate of the nonseparable model by Adam; returns (pars [P] ndarray, target_value_hist [N_opt])."""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    Y = torch.as_tensor(Y, dtype=torch.float64)
+    N, M = Y.shape
+    T = M * (M + 1) // 2
+    p0 = torch.as_tensor(np.asarray(pars0, dtype=np.float64))
+    tilde_l = p0[:N].clone().requires_grad_(True)
+    uL_vecs = p0[N:N + N * T].clone().requires_grad_(True)
+    tilde_sigma2_err = p0[-1:].clone().requires_grad_(True)
+    optimizer = torch.optim.Adam([{"params": tilde_l, "lr": lr}, {"params": [uL_vecs, tilde_sigma2_err], "lr": lr}])
+    hist = np.zeros(N_opt)
+
+    def flat():
+        return torch.cat([tilde_l, uL_vecs, tilde_sigma2_err.view(1)])
+
+    for i in range(N_opt):
+        optimizer.zero_grad()
+        out = logpos.nlogpos_obj_SVC(flat(), Y, x, **hyper_pars, verbose=True)
+        NegLog = out[0]
+        NegLog.backward()
+        optimizer.step()
+        hist[i] = -float(NegLog.detach())
+        if verbose:
+            print("iter %d: loglik %.6g lp_l %.6g lp_uL %.6g lp_s2 %.6g  -> %.8g" % (
+                i, float(out[1]), float(out[2]), float(out[3]), float(out[4]), hist[i]))
+        if callback is not None:
+            callback(i, hist[i])
+        if checkpoint_path and i % checkpoint_every == checkpoint_every - 1:
+            with open(checkpoint_path, "wb") as f:          # same on-disk format as the reference's MAP.dat
+                pickle.dump(flat().detach().numpy(), f)
+    pars = flat().detach().numpy().copy()
+    if checkpoint_path:
+        with open(checkpoint_path, "wb") as f:
+            pickle.dump(pars, f)
+    return pars, hist
+
+
+class HMCSampler:
+    """Hamiltonian Monte Carlo with a (optionally dense) constant mass matrix.
+
+    potential_func(position_tensor, **kwargs) -> scalar tensor (the NEGATIVE log posterior, e.g.
+    ``logpos.nlogpos_obj_SVC``); gradients come from ``torch.autograd.grad`` (one fused GPU evaluation each).
+    """
+
+    def __init__(self, sample_size, potential_func, init_position, step_size=1e-4, num_steps_in_leap=20,
+                 adaptive_step_size=False, M=None, duplicate_samples=True, TensorType=settings.torchType, seed=None,
+                 target_accept=0.8, **kwargs):
+        self.sample_size = int(sample_size)
+        self.potential_func = potential_func
+        self.q0 = np.asarray(init_position, dtype=np.float64).reshape(-1).copy()
+        self.step_size = float(step_size)
+        self.L = int(num_steps_in_leap)
+        self.adaptive = bool(adaptive_step_size)
+        self.duplicate_samples = bool(duplicate_samples)
+        self.kwargs = kwargs
+        self.rng = np.random.default_rng(seed)
+        self.target_accept = target_accept
+        P = self.q0.shape[0]
+        if M is None:
+            self.Mchol = None
+            self.Minv = None
+        else:
+            M = np.asarray(M, dtype=np.float64)
+            if M.shape != (P, P):
+                raise ValueError("mass matrix must be [P, P]")
+            self.Mchol = np.linalg.cholesky(M)
+            self.Minv = np.linalg.inv(M)
+
+    # -- pieces ------------------------------------------------------------------------------------
+    def potential_and_grad(self, q):
+        qt = torch.from_numpy(np.ascontiguousarray(q)).clone().requires_grad_(True)
+        U = self.potential_func(qt, **self.kwargs)
+        (g,) = torch.autograd.grad(U, qt)
+        return float(U.detach()), g.numpy().copy()
+
+    def kinetic(self, p):
+        return 0.5 * float(p @ (p if self.Minv is None else self.Minv @ p))
+
+    def draw_momentum(self, P):
+        z = self.rng.standard_normal(P)
+        return z if self.Mchol is None else self.Mchol @ z
+
+    def velocity(self, p):
+        return p if self.Minv is None else self.Minv @ p
+
+    def leapfrog(self, q, p, g, eps):
+        """L leapfrog steps from (q, p) with the gradient g at q; returns (q, p, U, g) at the end point."""
+        p = p - 0.5 * eps * g
+        U = None
+        for step in range(self.L):
+            q = q + eps * self.velocity(p)
+            U, g = self.potential_and_grad(q)
+            if not np.isfinite(U):
+                return q, p, np.inf, g
+            p = p - (eps if step < self.L - 1 else 0.5 * eps) * g
+        return q, p, U, g
+
+    # -- the loop -----------------------------------------------------------------------------------
+    def main_hmc_loop(self):
+        P = self.q0.shape[0]
+        q = self.q0.copy()
+        U, g = self.potential_and_grad(q)
+        samples = np.zeros((self.sample_size, P))
+        accepted = 0
+        energy_err = np.zeros(self.sample_size)
+        eps = self.step_size
+        kept = 0
+        it = 0
+        while kept < self.sample_size:
+            p0 = self.draw_momentum(P)
+            H0 = U + self.kinetic(p0)
+            try:
+                q1, p1, U1, g1 = self.leapfrog(q, p0, g, eps)
+                H1 = U1 + self.kinetic(p1)
+            except RuntimeError:                  # covariance left the positive definite cone: reject
+                U1, H1 = np.inf, np.inf
+            dH = H1 - H0
+            acc = np.isfinite(dH) and (np.log(self.rng.random()) < -dH)
+            if acc:
+                q, U, g = q1, U1, g1
+                accepted += 1
+            if acc or self.duplicate_samples:
+                samples[kept] = q
+                energy_err[kept] = dH if np.isfinite(dH) else np.nan
+                kept += 1
+            it += 1
+            if self.adaptive and it <= max(50, self.sample_size // 2):
+                # simple Robbins-Monro adaptation towards the target acceptance probability
+                a = min(1.0, float(np.exp(-dH))) if np.isfinite(dH) else 0.0
+                eps *= float(np.exp((a - self.target_accept) / np.sqrt(it)))
+        info = {"accept_rate": accepted / max(it, 1), "step_size": eps, "energy_error": energy_err, "iterations": it}
+        return samples, info
+
+
+def sampler(**kw):
+    """Alias with the reference's constructor spelling: ``HMC_Sampler.HMC_sampler.sampler(...)``."""
+    return HMCSampler(**kw)
