@@ -99,7 +99,7 @@ static void free_priors(nmgp_ctx* c) {
 
 static void free_subject(nmgp_ctx* c) {
     double** ptrs[] = {&c->d_x, &c->d_Y, &c->d_y, &c->d_pars, &c->d_grad, &c->d_ell, &c->d_sig, &c->d_Lv,
-                       &c->d_S, &c->d_z, &c->d_alpha, &c->d_R, &c->d_R2, &c->d_part, &c->d_K, &c->d_K2,
+                       &c->d_S, &c->d_Sinv, &c->d_z, &c->d_alpha, &c->d_R, &c->d_R2, &c->d_part, &c->d_K, &c->d_K2,
                        &c->d_w, &c->d_E};
     for (double** p : ptrs) {
         if (*p) hipFree(*p);
@@ -240,7 +240,8 @@ extern "C" int nmgp_set_data(nmgp_ctx* c, const double* x, const double* Y, int 
 
 int nmgp_ensure_S(nmgp_ctx* c) {
     const size_t n = c->n;
-    const size_t ld = ((n + 1 + 15) / 16) * 16;      // one extra row (the right-hand side rides below the matrix), even ld
+    // rows: n (matrix) + 1 (right-hand side y) + n (identity -> L^-T, gradient path); even leading dimension
+    const size_t ld = ((2 * n + 2 + 15) / 16) * 16;
     if (!c->d_S || c->S_cap < ld * n) {
         NMGP_TRY(nmgp_dev_alloc(c, &c->d_S, ld * n));
         c->S_cap = ld * n;
@@ -302,7 +303,7 @@ static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
 
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
     if (c->chol_algo == 1 && (ld % 2 == 0)) {
-        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, c->chol_nb1, d_info, 1, 0, 0);
+        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0);
         return 0;
     }
     if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
@@ -343,19 +344,27 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         int r = svc_cov_build(s, c->d_x, c->d_ell, c->d_Lv, c->d_pars + (P - 1), c->d_S, ld, N, M, false);
         if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     }
-    if (c->chol_algo == 1) {
+    const bool custom = (c->chol_algo == 1);
+    const int xpad = (n + 1) & 1;            // rows between y and the identity block
+    const int xoff = n + 1 + xpad;           // first row of X = L^-T (even)
+    if (custom) {
         {
             StageScope sp(c, NMGP_STAGE_CHOL);
             set_row(s, c->d_S, ld, n, c->d_y, n, 1, 0, 0);              // y rides along as row n
-            NMGP_TRY(nmgp_chol_factor(c, c->d_S, ld, n, 1, c->d_info));   // row n becomes z = L^-1 y
+            // with gradient: a zero pad row (keeps the next block at an even offset) and n identity rows -> X = L^-T
+            if (want_grad) identity_rows(s, c->d_S, ld, n + 1, n, xpad);
+            // row n becomes z = L^-1 y
+            potrf_lower(s, c->stream2, chol_events(c, n), c->d_S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0,
+                        c->chol_nb1, c->d_info, 1, 0, 0);
         }
         {
             StageScope sp(c, NMGP_STAGE_SOLVE);
             get_row(s, c->d_S, ld, n, c->d_z, n, 1, 0, 0);
             if (want_grad) {
-                HIP_TRY(c, hipMemcpyAsync(c->d_alpha, c->d_z, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-                BLAS_TRY(c, rocblas_dtrsv(c->blas, rocblas_fill_lower, rocblas_operation_transpose,
-                                          rocblas_diagonal_non_unit, n, c->d_S, ld, c->d_alpha, 1));
+                // alpha = Sigma^-1 y = L^-T z = X z
+                const double one = 1.0, zero = 0.0;
+                BLAS_TRY(c, rocblas_dgemv(c->blas, rocblas_operation_none, n, n, &one, c->d_S + xoff, ld, c->d_z, 1,
+                                          &zero, c->d_alpha, 1));
             }
         }
     } else {
@@ -413,15 +422,29 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
                      ig_const, prior, sc + SC_OUT);
     }
     if (want_grad) {
+        const double* Sinv = c->d_S;
+        int ldi = ld;
+        double ssign = 1.0;
         {
             StageScope sp(c, NMGP_STAGE_INVERSE);
-            BLAS_TRY(c, rocsolver_dpotri(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info + 2));
-            fill_lower_to_full(s, c->d_S, ld, n);
+            if (custom) {
+                // -Sigma^-1 = -(L^-T)(L^-T)^T: one more MFMA SYRK over the triangular X (k-panels left of a tile skipped)
+                if (!c->d_Sinv) NMGP_TRY(nmgp_dev_alloc(c, &c->d_Sinv, (size_t)n * n));
+                HIP_TRY(c, hipMemsetAsync(c->d_Sinv, 0, (size_t)n * n * sizeof(double), s));
+                syrk_lower(s, c->d_S + xoff, ld, c->d_Sinv, n, n, n, n, 1, 0, 0, 1);
+                fill_lower_to_full(s, c->d_Sinv, n, n);
+                Sinv = c->d_Sinv;
+                ldi = n;
+                ssign = -1.0;
+            } else {
+                BLAS_TRY(c, rocsolver_dpotri(c->blas, rocblas_fill_lower, n, c->d_S, ld, c->d_info + 2));
+                fill_lower_to_full(s, c->d_S, ld, n);
+            }
         }
         {
             StageScope sp(c, NMGP_STAGE_ADJOINT);
-            trace_terms(s, c->d_alpha, c->d_S, ld, n, sc + SC_TRACE);
-            int r = svc_adjoint(s, c->d_x, c->d_ell, c->d_Lv, c->d_alpha, c->d_S, ld, N, M, c->d_part);
+            trace_terms(s, c->d_alpha, Sinv, ldi, n, sc + SC_TRACE, ssign);
+            int r = svc_adjoint(s, c->d_x, c->d_ell, c->d_Lv, c->d_alpha, Sinv, ldi, N, M, c->d_part, ssign);
             if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
             svc_grad_final(s, c->d_part, (N + 63) / 64, N, M, c->d_Lv, c->d_R2, N, c->d_pars, sc + SC_TRACE, a, b,
                            prior, c->d_grad);
@@ -556,7 +579,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     {
         StageScope sp(c, NMGP_STAGE_CHOL);
         set_row(s, c->b_S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
-        potrf_lower(s, c->stream2, chol_events(c, n), c->b_S, ld, n, 1, c->chol_nb1, c->b_info, B, bs, 1);
+        potrf_lower(s, c->stream2, chol_events(c, n), c->b_S, ld, n, 1, 0, c->chol_nb1, c->b_info, B, bs, 1);
     }
     {
         StageScope sp(c, NMGP_STAGE_SOLVE);
@@ -657,7 +680,7 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     if (algo == 1) {
         StageScope sp(c, NMGP_STAGE_CHOL);
         if (rhs) set_row(s, dA, (int)ld, n, dv, n, 1, 0, 0);
-        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
+        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
         if (rhs) get_row(s, dA, (int)ld, n, dv + n, n, 1, 0, 0);
     } else {
         StageScope sp(c, NMGP_STAGE_CHOL);

@@ -42,13 +42,14 @@ __device__ inline double2 load2_guard(const double* __restrict__ p, int r, int r
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
 __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C,
-                                                        int ldc, int mrows, int ncols, int K, long long bstride) {
+                                                        int ldc, int mrows, int ncols, int K, long long bstride,
+                                                        long long cstride, int ktri) {
     __shared__ double sA[2][SY_BK * SY_LD];
     __shared__ double sB[2][SY_BK * SY_LD];
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (bi < bj) return;
     A += (size_t)blockIdx.z * bstride;       // batch of independent matrices (one per chain), same shape
-    C += (size_t)blockIdx.z * bstride;
+    C += (size_t)blockIdx.z * cstride;
     const bool diag = (bi == bj);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
@@ -82,7 +83,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     // a wave whose 64x64 sub-tile lies strictly above the diagonal has nothing to compute
     const bool active = !(diag && wi < wj);
     const int nk = (K + SY_BK - 1) / SY_BK;
-    gload(0);
+    // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
+    // first row contribute nothing
+    const int kt0 = ktri ? (row0 / SY_BK) : 0;
+    gload(kt0 * SY_BK);
     // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
     // the MFMA negated, so the k-loop leaves C - A A^T in registers and the epilogue is stores only.
     // D[row = (lane>>4) + 4 reg <-> j][col = lane&15 <-> i]
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
             }
     sstore(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) gload((kt + 1) * SY_BK);
         if (active) {
             const double* tA = sA[cur];
@@ -138,10 +142,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
 }
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride) {
+                long long bstride, long long cstride, int ktri) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
-    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride);
+    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride,
+                       cstride < 0 ? bstride : cstride, ktri);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,46 +369,52 @@ void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n,
     hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
 }
 
-static void factor_panel(hipStream_t s, double* A, int lda, int m, int c0, int w1, int* info, int batch,
-                         long long bs, int is) {
+// rows that take part when the factorisation has reached column `cend`: the n matrix rows, the `extra` dense rows
+// (right-hand sides) and the first `cend` of the `xtri` identity rows (row r of L^-T is zero left of column r)
+static inline int active_rows(int n, int extra, int xtri, int cend) { return n + extra + (cend < xtri ? cend : xtri); }
+
+static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w1, int* info,
+                         int batch, long long bs, int is) {
     for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
         const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
         double* Ajj = A + (size_t)j0 * lda + j0;
         potf2_64(s, Ajj, lda, jb, info, j0, batch, bs, is);
-        const int below = m - (j0 + jb);
+        const int below = active_rows(n, extra, xtri, j0 + jb) - (j0 + jb);
         if (below > 0) {
             double* Apan = A + (size_t)j0 * lda + (j0 + jb);
             trsm_64(s, Ajj, lda, jb, Apan, lda, below, batch, bs);
             const int ncols = c0 + w1 - (j0 + jb);
             if (ncols > 0)
-                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs);
+                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1,
+                           0);
         }
     }
 }
 
-// Blocked Cholesky of the n x n lower triangle of A with `extra` additional rows below it (rows n .. n+extra-1 of
-// the same array) that are carried through the panel solves and updates: on exit they hold  R L^-T.
-//
+// Blocked Cholesky of the n x n lower triangle of A.  Below the matrix the same array may hold
+//   * `extra` dense rows R (rows n .. n+extra-1): on exit R L^-T (a right-hand side y becomes z = L^-1 y), and
+//   * `xtri` identity rows (rows n+extra .. n+extra+xtri-1, initialised to I by the caller): on exit L^-T, from which
+//     Sigma^-1 = (L^-T)(L^-T)^T follows with one more SYRK.  Row r of L^-T is zero left of column r, so only the
+//     first `cend` of these rows take part while the factorisation is at column cend (n^3/3 extra flop, not n^3).
 // Look-ahead over two streams: after panel k is factored on `s`, only the NEXT panel's columns are updated on `s`
 // (so that panel k+1 can start at once) while the rest of the trailing matrix is updated on `s2`, concurrently with
 // the latency-bound 64-wide steps of panel k+1.  ev[] must hold at least 2 * ceil(n / nb1) + 1 events; s2 == nullptr
 // (or ev == nullptr) selects the plain single-stream order.
 // batch > 1 factors `batch` matrices of identical shape at once (matrix b at A + b * bstride, status word at
 // info + b * istride): every launch covers all of them, so the latency of the 64-wide steps is paid once per batch.
-void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
-                 int* info, int batch, long long bstride, int istride) {
+void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
+                 int nb1, int* info, int batch, long long bstride, int istride) {
     const int is = istride;
     const long long bs = bstride;
-    const int m = n + extra;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
     if (!la) {
         for (int c0 = 0; c0 < n; c0 += nb1) {
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
-            factor_panel(s, A, lda, m, c0, w1, info, batch, bs, is);
+            factor_panel(s, A, lda, n, extra, xtri, c0, w1, info, batch, bs, is);
             const int c1 = c0 + w1;
             if (c1 < n)
-                syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, n - c1, w1, batch,
-                           bs);
+                syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda,
+                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0);
         }
         return;
     }
@@ -418,20 +429,36 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         const int w1n = (c1 < n) ? ((n - c1 < nb1) ? (n - c1) : nb1) : 0;
         const int c2 = c1 + w1n;
         hipEvent_t evPanel = ev[1 + 2 * k], evB = ev[2 + 2 * k];
-        factor_panel(s, A, lda, m, c0, w1, info, batch, bs, is);
+        factor_panel(s, A, lda, n, extra, xtri, c0, w1, info, batch, bs, is);
         if (c1 >= n) break;
         hipEventRecord(evPanel, s);
         // the previous far update also wrote the next panel's columns
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
-        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, m - c1, w1n, w1, batch, bs);
+        const int mact = active_rows(n, extra, xtri, c1);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, mact - c1, w1n, w1, batch, bs, -1,
+                   0);
         prevB = false;
         if (c2 < n) {
             hipStreamWaitEvent(s2, evPanel, 0);
-            syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, m - c2, n - c2, w1, batch, bs);
+            syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, mact - c2, n - c2, w1, batch,
+                       bs, -1, 0);
             hipEventRecord(evB, s2);
             prevB = true;
         }
     }
+    // the caller continues on s: it must see the last far update
+    if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
+}
+
+// rows [row0, row0 + pad) := 0 and rows [row0 + pad, row0 + pad + n) := identity (the seed of L^-T) in the n columns
+// of A.  The pad row keeps the identity block at an even row offset (16-byte vector loads of the later SYRK).
+__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ A, int lda, int row0, int n, int pad) {
+    const int r = blockIdx.x * 256 + threadIdx.x;          // 0 .. pad + n - 1
+    const int c = blockIdx.y;
+    if (r < n + pad) A[(size_t)c * lda + row0 + r] = (r - pad == c) ? 1.0 : 0.0;
+}
+void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad) {
+    hipLaunchKernelGGL(k_identity_rows, dim3(cdiv_c(n + pad, 256), n), dim3(256), 0, s, A, lda, row0, n, pad);
 }
 
 }  // namespace nmgpk

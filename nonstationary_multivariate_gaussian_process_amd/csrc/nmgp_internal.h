@@ -61,7 +61,8 @@ struct nmgp_ctx {
     double* d_ell = nullptr;    // [N]    exp(tilde_l)
     double* d_sig = nullptr;    // [N]    exp(tilde_sigma) (separable)
     double* d_Lv = nullptr;     // [N, T] packed tril factors, exp applied on the diagonal slots
-    double* d_S = nullptr;      // [n, n] covariance / factor / inverse (lower, column-major)
+    double* d_S = nullptr;      // [ldS, n] covariance / factor (lower, column-major) + rows for y and for L^-T
+    double* d_Sinv = nullptr;   // [n, n] -Sigma^-1 (gradient path of the custom factorisation)
     size_t S_cap = 0;
     int ldS = 0;
     double* d_z = nullptr;      // [n]   L^-1 y, then alpha = Sigma^-1 y
@@ -170,8 +171,9 @@ void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l,
                    int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part);
-void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out);
+                const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0);
+void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out,
+                 double ssign = 1.0);
 void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
                     int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad);
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
@@ -215,7 +217,8 @@ void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_
 void add_diag(hipStream_t s, double* A, int ld, int n, double v);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride);
+                long long bstride, long long cstride = -1, int ktri = 0);
+void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad);
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride);
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
@@ -224,7 +227,7 @@ void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n,
              long long vstride);
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
              long long vstride);
-void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int nb1,
-                 int* info, int batch, long long bstride, int istride);
+void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
+                 int nb1, int* info, int batch, long long bstride, int istride);
 
 }  // namespace nmgpk

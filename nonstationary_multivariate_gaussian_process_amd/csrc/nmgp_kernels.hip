@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
                                                       const double* __restrict__ Lv,
                                                       const double* __restrict__ alpha,
                                                       const double* __restrict__ Sinv, int ld, int N,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part, double ssign) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T], sa[TJ * M];
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
             for (int mp = 0; mp < M; ++mp) {
                 const double* col = Sinv + ((size_t)mp * Ns + j) * ld;
 #pragma unroll
-                for (int m = 0; m < M; ++m) G[m][mp] = 0.5 * (ai[m] * sa[k * M + mp] - col[(size_t)m * Ns + i]);
+                for (int m = 0; m < M; ++m) G[m][mp] = 0.5 * (ai[m] * sa[k * M + mp] - ssign * col[(size_t)m * Ns + i]);
             }
             double H = 0.0;
 #pragma unroll
@@ -511,10 +511,12 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
     }
 }
 
+// ssign = +1 when Sinv holds Sigma^-1 (rocSOLVER potri), -1 when it holds -Sigma^-1 (C -= X X^T of the custom path)
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part) {
+                const double* Sinv, int ld, int N, int M, double* part, double ssign) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64));
-#define NMGP_ADJ(MM) hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part)
+#define NMGP_ADJ(MM) \
+    hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign)
     switch (M) {
         case 1: NMGP_ADJ(1); break;
         case 2: NMGP_ADJ(2); break;
@@ -533,7 +535,7 @@ int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double*
 // trace term: out[0] = sum_r alpha_r^2, out[1] = sum_r Sinv[r, r]
 __global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__ alpha,
                                                        const double* __restrict__ Sinv, int ld, int n,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, double ssign) {
     __shared__ double sh[16];
     double a = 0.0, d = 0.0;
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
@@ -544,12 +546,12 @@ __global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__
     d = block_sum(d, sh);
     if (threadIdx.x == 0) {
         out[0] = a;
-        out[1] = d;
+        out[1] = ssign * d;
     }
 }
 
-void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out) {
-    hipLaunchKernelGGL(k_trace_terms, dim3(1), dim3(1024), 0, s, alpha, Sinv, ld, n, out);
+void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out, double ssign) {
+    hipLaunchKernelGGL(k_trace_terms, dim3(1), dim3(1024), 0, s, alpha, Sinv, ld, n, out, ssign);
 }
 
 // Assemble d NegLog / d pars from the adjoint partials, the prior solves and the scalar terms.
