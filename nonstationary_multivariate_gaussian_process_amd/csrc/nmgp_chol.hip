@@ -373,8 +373,15 @@ void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n,
 // (right-hand sides) and the first `cend` of the `xtri` identity rows (row r of L^-T is zero left of column r)
 static inline int active_rows(int n, int extra, int xtri, int cend) { return n + extra + (cend < xtri ? cend : xtri); }
 
-static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w1, int* info,
-                         int batch, long long bs, int is) {
+// Factor the panel of columns [c0, c0 + w) (already up to date) together with all active rows below it.
+// Two schedules with the same launch count:
+//  * right-looking 64-wide steps (each step updates the rest of the panel with K = 64): shortest critical path, used
+//    for a single matrix, where every launch is latency-bound anyway;
+//  * recursive halving (left half, ONE update of the right half with K = half width, right half): touches the panel's
+//    C entries log2(w/64) times instead of w/128 times and runs only a quarter of the update flop at K = 64 (HBM-bound
+//    at 8 flop/byte), the rest at K = 128 / 256: used for batches, where the launches are throughput-bound.
+static void factor_panel_rl(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w1, int* info,
+                            int batch, long long bs, int is) {
     for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
         const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
         double* Ajj = A + (size_t)j0 * lda + j0;
@@ -389,6 +396,33 @@ static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, in
                            0);
         }
     }
+}
+
+static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
+                             int batch, long long bs, int is) {
+    if (w <= 64) {
+        double* Ajj = A + (size_t)c0 * lda + c0;
+        potf2_64(s, Ajj, lda, w, info, c0, batch, bs, is);
+        const int below = active_rows(n, extra, xtri, c0 + w) - (c0 + w);
+        if (below > 0) trsm_64(s, Ajj, lda, w, A + (size_t)c0 * lda + (c0 + w), lda, below, batch, bs);
+        return;
+    }
+    int h = ((w / 2 + 63) / 64) * 64;                       // left width: a multiple of 64, at least half
+    if (h >= w) h = ((w - 1) / 64) * 64;
+    factor_panel_rec(s, A, lda, n, extra, xtri, c0, h, info, batch, bs, is);
+    const int c1 = c0 + h;
+    const int below = active_rows(n, extra, xtri, c1) - c1;
+    if (below > 0)
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0);
+    factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
+}
+
+static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
+                         int batch, long long bs, int is) {
+    if (batch >= 4)
+        factor_panel_rec(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+    else
+        factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
 }
 
 // Blocked Cholesky of the n x n lower triangle of A.  Below the matrix the same array may hold
