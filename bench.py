@@ -90,15 +90,13 @@ def main():
     want_grad = bool(a.grad)
     B = max(1, a.chains)
     if B > 1:
-        if want_grad:
-            raise SystemExit("--chains > 1 is the value-only batched path")
         ctx.svc_batch_alloc(B)
         # chain b starts from its own smooth perturbation of the generating parameters
         ctx.svc_batch_set_pars(np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * b) for b in range(B)]))
 
     def step():
         if B > 1:
-            ctx.svc_batch_eval(hv, True)
+            ctx.svc_batch_eval(hv, True, want_grad)
             o, st = ctx.svc_batch_fetch()
             if st.any():
                 raise RuntimeError("chain failed: %s" % st)

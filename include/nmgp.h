@@ -86,7 +86,7 @@ int nmgp_svc_fetch(nmgp_ctx* ctx, double out5[5], double* grad);
 
 /* Batched form: B chains of the resident subject (same x, Y; B parameter vectors stacked [B, P]) are evaluated by ONE
  * launch sequence -- every kernel takes the chain as a grid dimension, so the latency-bound panel steps of the
- * factorisation are paid once per batch.  Value only (verbose 5-tuples).  This is the throughput path of MCMC with
+ * factorisation are paid once per batch.  This is the throughput path of MCMC with
  * many chains (the reference runs its chains as separate processes, Nonseparable_model_mpisim.py:305-306).
  * nmgp_svc_batch_alloc sizes B covariance buffers (B * 8 * MN * (MN+1) bytes); nmgp_svc_batch_eval only enqueues;
  * nmgp_svc_batch_fetch synchronises and returns out[B,5] and per-chain status[B] (0 ok; k>0 leading minor k not
@@ -94,8 +94,11 @@ int nmgp_svc_fetch(nmgp_ctx* ctx, double out5[5], double* grad);
 int nmgp_svc_batch_alloc(nmgp_ctx* ctx, int B);
 int nmgp_svc_batch_set_pars(nmgp_ctx* ctx, const double* pars);
 double* nmgp_svc_batch_pars_dev(nmgp_ctx* ctx);
-int nmgp_svc_batch_eval(nmgp_ctx* ctx, const double hyper[8], int prior);
+int nmgp_svc_batch_eval(nmgp_ctx* ctx, const double hyper[8], int prior, int want_grad);
 int nmgp_svc_batch_fetch(nmgp_ctx* ctx, double* out, int* status);
+/* gradients d NegLog / d pars of the last batched evaluation (want_grad = 1): [B, P] on the host / in HBM */
+int nmgp_svc_batch_fetch_grad(nmgp_ctx* ctx, double* grad);
+double* nmgp_svc_batch_grad_dev(nmgp_ctx* ctx);
 
 /* Dense covariance of the nonseparable model as the reference assembles it (logpos.py:339-353:
  * K_x, generate_K_index_SVC, the n-major->m-major permutation, kron(ones, K_x) * K_i, + sigma2 I).

@@ -42,7 +42,9 @@ SIGNATURES = {
     "nmgp_svc_batch_alloc": (I, [V, I]),
     "nmgp_svc_batch_set_pars": (I, [V, P]),
     "nmgp_svc_batch_pars_dev": (V, [V]),
-    "nmgp_svc_batch_eval": (I, [V, P, I]),
+    "nmgp_svc_batch_eval": (I, [V, P, I, I]),
+    "nmgp_svc_batch_fetch_grad": (I, [V, P]),
+    "nmgp_svc_batch_grad_dev": (V, [V]),
     "nmgp_svc_batch_fetch": (I, [V, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_covariance": (I, [V, P, P]),
     "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
@@ -215,9 +217,14 @@ class Context:
         self.check(self.lib.nmgp_svc_batch_set_pars(self.h, ptr(pars)))
         self.sync()
 
-    def svc_batch_eval(self, hyper, prior=True):
+    def svc_batch_eval(self, hyper, prior=True, want_grad=False):
         hyper = as_f64(hyper)
-        self.check(self.lib.nmgp_svc_batch_eval(self.h, ptr(hyper), int(bool(prior))))
+        self.check(self.lib.nmgp_svc_batch_eval(self.h, ptr(hyper), int(bool(prior)), int(bool(want_grad))))
+
+    def svc_batch_fetch_grad(self):
+        grad = np.empty((self.B, self.N * (1 + self.T) + 1))
+        self.check(self.lib.nmgp_svc_batch_fetch_grad(self.h, ptr(grad)))
+        return grad
 
     def svc_batch_fetch(self):
         out = np.empty((self.B, 5))

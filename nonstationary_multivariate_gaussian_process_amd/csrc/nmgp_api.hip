@@ -108,7 +108,9 @@ static void free_subject(nmgp_ctx* c) {
     c->S_cap = c->K_cap = c->part_cap = 0;
     free_priors(c);
     {
-        double** bp[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q};
+        double** bp[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
+                         &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr};
+        c->b_grad_ready = false;
         for (double** p : bp) {
             if (*p) hipFree(*p);
             *p = nullptr;
@@ -508,7 +510,9 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 // the forward path takes the chain index as a grid dimension.  The 96 latency-bound 64-wide panel steps of the
 // Cholesky are then paid once per batch instead of once per chain, and the MFMA trailing updates fill the chip.
 static void free_batch(nmgp_ctx* c) {
-    double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q};
+    double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
+                       &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr};
+    c->b_grad_ready = false;
     for (double** p : ptrs) {
         if (*p) hipFree(*p);
         *p = nullptr;
@@ -553,14 +557,34 @@ extern "C" int nmgp_svc_batch_set_pars(nmgp_ctx* c, const double* pars) {
 
 extern "C" double* nmgp_svc_batch_pars_dev(nmgp_ctx* c) { return c ? c->b_pars : nullptr; }
 
-extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior) {
+static int batch_grad_alloc(nmgp_ctx* c) {
+    if (c->b_grad_ready) return 0;
+    const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc, B = c->batch;
+    const size_t ld2 = ((2 * n + 2 + 15) / 16) * 16;
+    const size_t NJ = (N + 63) / 64;
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_S2, B * ld2 * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_Sinv, B * n * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_alpha, B * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_part, B * NJ * N * (T + 1)));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_grad, B * P));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_R2, N * B * (1 + T)));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_tr, B * 2));
+    c->b_grad_ready = true;
+    return 0;
+}
+
+extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior, int want_grad) {
     if (!c) return NMGP_E_NULL;
     if (!hyper) return nmgp_fail(c, NMGP_E_NULL, "hyper must not be NULL");
     if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->N, M = c->M, T = c->T, n = c->n, B = c->batch;
     const long long P = c->P_svc;
-    const int ld = (int)((((size_t)n + 1 + 15) / 16) * 16);
+    if (want_grad) NMGP_TRY(batch_grad_alloc(c));
+    // value-only: rows = n + 1 (y); with gradient: + pad + n identity rows (-> L^-T), in the larger buffer
+    const int xpad = (n + 1) & 1, xoff = n + 1 + xpad;
+    const int ld = want_grad ? (int)((((size_t)2 * n + 2 + 15) / 16) * 16) : (int)((((size_t)n + 1 + 15) / 16) * 16);
+    double* S = want_grad ? c->b_S2 : c->b_S;
     const long long bs = (long long)ld * n;
     const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
     const double a = hyper[6], b = hyper[7];
@@ -573,40 +597,55 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
-        int r = svc_cov_build(s, c->d_x, c->b_ell, c->b_Lv, c->b_pars + (P - 1), c->b_S, ld, N, M, false, B, bs);
+        int r = svc_cov_build(s, c->d_x, c->b_ell, c->b_Lv, c->b_pars + (P - 1), S, ld, N, M, false, B, bs);
         if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     }
     {
         StageScope sp(c, NMGP_STAGE_CHOL);
-        set_row(s, c->b_S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
-        potrf_lower(s, c->stream2, chol_events(c, n), c->b_S, ld, n, 1, 0, c->chol_nb1, c->b_info, B, bs, 1);
+        set_row(s, S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
+        if (want_grad) identity_rows(s, S, ld, n + 1, n, xpad, B, bs);
+        potrf_lower(s, c->stream2, chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
+                    c->b_info, B, bs, 1);
     }
     {
         StageScope sp(c, NMGP_STAGE_SOLVE);
-        get_row(s, c->b_S, ld, n, c->b_z, n, B, bs, n);
+        get_row(s, S, ld, n, c->b_z, n, B, bs, n);
+        if (want_grad) {
+            const double one = 1.0, zero = 0.0;               // alpha_b = X_b z_b
+            BLAS_TRY(c, rocblas_dgemv_strided_batched(c->blas, rocblas_operation_none, n, n, &one, S + xoff, ld, bs,
+                                                      c->b_z, 1, n, &zero, c->b_alpha, 1, n, B));
+        }
     }
     {
         StageScope sp(c, NMGP_STAGE_REDUCE);
-        chol_logdet_quad(s, c->b_S, ld, n, c->b_z, c->b_scal, c->b_scal + 1, B, bs, 16);
+        chol_logdet_quad(s, S, ld, n, c->b_z, c->b_scal, c->b_scal + 1, B, bs, 16);
     }
     {
         StageScope sp(c, NMGP_STAGE_PRIOR);
         const double one = 1.0;
         svc_prior_rhs(s, c->b_pars, N, T, mu_l, mu_L, c->b_R, N, B);
-        if (pl == pL) {
-            // one multi-right-hand-side solve for the whole batch: the prior factor depends on (x, alpha, beta) only
-            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                      rocblas_diagonal_non_unit, N, B * (1 + T), &one, pl->L, pl->ld, c->b_R, N));
-        } else {
-            for (int z = 0; z < B; ++z) {
-                double* Rz = c->b_R + (size_t)z * (1 + T) * N;
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, Rz, N));
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, Rz + N, N));
+        const bool same = (pl == pL);
+        for (int pass = 0; pass < ((want_grad && prior) ? 2 : 1); ++pass) {
+            double* R = pass == 0 ? c->b_R : c->b_R2;
+            const rocblas_operation op = pass == 0 ? rocblas_operation_none : rocblas_operation_transpose;
+            if (pass == 1)
+                HIP_TRY(c, hipMemcpyAsync(c->b_R2, c->b_R, (size_t)N * B * (1 + T) * sizeof(double),
+                                          hipMemcpyDeviceToDevice, s));
+            if (same) {
+                // one multi-right-hand-side solve for the whole batch: the prior factor depends on (x, alpha, beta) only
+                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
+                                          B * (1 + T), &one, pl->L, pl->ld, R, N));
+            } else {
+                for (int z = 0; z < B; ++z) {
+                    double* Rz = R + (size_t)z * (1 + T) * N;
+                    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                                              rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, Rz, N));
+                    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                                              rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, Rz + N, N));
+                }
             }
+            if (pass == 0) col_sumsq(s, c->b_R, N, N, B * (1 + T), c->b_q);
         }
-        col_sumsq(s, c->b_R, N, N, B * (1 + T), c->b_q);
     }
     {
         StageScope sp(c, NMGP_STAGE_REDUCE);
@@ -614,7 +653,39 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         svc_finalize(s, c->b_scal, c->b_scal + 1, c->b_q, pl->logdet, pL->logdet, c->b_pars, P, N, T, a, b, ig_const,
                      prior, c->b_scal + 8, B, 16);
     }
+    if (want_grad) {
+        {
+            StageScope sp(c, NMGP_STAGE_INVERSE);
+            HIP_TRY(c, hipMemsetAsync(c->b_Sinv, 0, (size_t)B * n * n * sizeof(double), s));
+            syrk_lower(s, S + xoff, ld, c->b_Sinv, n, n, n, n, B, bs, (long long)n * n, 1);     // -Sigma^-1 = -X X^T
+            fill_lower_to_full(s, c->b_Sinv, n, n, B);
+        }
+        {
+            StageScope sp(c, NMGP_STAGE_ADJOINT);
+            trace_terms(s, c->b_alpha, c->b_Sinv, n, n, c->b_tr, -1.0, B);
+            int r = svc_adjoint(s, c->d_x, c->b_ell, c->b_Lv, c->b_alpha, c->b_Sinv, n, N, M, c->b_part, -1.0, B);
+            if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
+            svc_grad_final(s, c->b_part, (N + 63) / 64, N, M, c->b_Lv, c->b_R2, N, c->b_pars, c->b_tr, a, b, prior,
+                           c->b_grad, B);
+        }
+    }
+    c->b_last_grad = want_grad != 0;
     c->last_kind = 2;
+    return 0;
+}
+
+extern "C" double* nmgp_svc_batch_grad_dev(nmgp_ctx* c) { return c ? c->b_grad : nullptr; }
+
+// grad: [B, P] = d NegLog / d pars of every chain of the last batched evaluation (which must have asked for it)
+extern "C" int nmgp_svc_batch_fetch_grad(nmgp_ctx* c, double* grad) {
+    if (!c) return NMGP_E_NULL;
+    if (!grad) return nmgp_fail(c, NMGP_E_NULL, "grad must not be NULL");
+    if (c->last_kind != 2 || !c->b_last_grad)
+        return nmgp_fail(c, NMGP_E_STATE, "the last batched evaluation did not compute gradients");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(grad, c->b_grad, (size_t)c->batch * c->P_svc * sizeof(double), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

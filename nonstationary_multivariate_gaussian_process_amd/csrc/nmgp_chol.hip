@@ -486,13 +486,15 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
 
 // rows [row0, row0 + pad) := 0 and rows [row0 + pad, row0 + pad + n) := identity (the seed of L^-T) in the n columns
 // of A.  The pad row keeps the identity block at an even row offset (16-byte vector loads of the later SYRK).
-__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ A, int lda, int row0, int n, int pad) {
+__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ A, int lda, int row0, int n, int pad,
+                                                        long long bstride) {
     const int r = blockIdx.x * 256 + threadIdx.x;          // 0 .. pad + n - 1
     const int c = blockIdx.y;
-    if (r < n + pad) A[(size_t)c * lda + row0 + r] = (r - pad == c) ? 1.0 : 0.0;
+    if (r < n + pad) A[(size_t)blockIdx.z * bstride + (size_t)c * lda + row0 + r] = (r - pad == c) ? 1.0 : 0.0;
 }
-void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad) {
-    hipLaunchKernelGGL(k_identity_rows, dim3(cdiv_c(n + pad, 256), n), dim3(256), 0, s, A, lda, row0, n, pad);
+void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch, long long bstride) {
+    hipLaunchKernelGGL(k_identity_rows, dim3(cdiv_c(n + pad, 256), n, batch), dim3(256), 0, s, A, lda, row0, n, pad,
+                       bstride);
 }
 
 }  // namespace nmgpk

@@ -95,6 +95,16 @@ struct nmgp_ctx {
     double* b_scal = nullptr;   // [B, 16] : logdet, quad, out5...
     double* b_q = nullptr;      // [B (1 + T)]
     int* b_info = nullptr;      // [B]
+    // batched gradient state (allocated on the first batched value+gradient evaluation)
+    bool b_grad_ready = false;
+    double* b_S2 = nullptr;     // [B] x (ld2 x n): covariance + y row + pad + identity rows -> L^-T
+    double* b_Sinv = nullptr;   // [B] x (n x n): -Sigma^-1
+    double* b_alpha = nullptr;  // [B, n]
+    double* b_part = nullptr;   // [B, NJ, N, 1+T]
+    double* b_grad = nullptr;   // [B, P]
+    double* b_R2 = nullptr;     // [N, B (1+T)]
+    double* b_tr = nullptr;     // [B, 2]
+    bool b_last_grad = false;
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
 
@@ -165,17 +175,18 @@ void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const doubl
                       double* out_quad, int batch = 1, long long bstride = 0, int ostride = 0);
 void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out);
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out);
-void fill_lower_to_full(hipStream_t s, double* A, int ld, int n);
+void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch = 1);
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
 void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
                    int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0);
+                const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1);
 void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out,
-                 double ssign = 1.0);
+                 double ssign = 1.0, int batch = 1);
 void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
-                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad);
+                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad,
+                    int batch = 1);
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
                   double ig_const, int prior, double* out5, int batch = 1, int sstride = 0);
@@ -218,7 +229,7 @@ void add_diag(hipStream_t s, double* A, int ld, int n, double v);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride = -1, int ktri = 0);
-void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad);
+void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch = 1, long long bstride = 0);
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride);
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,

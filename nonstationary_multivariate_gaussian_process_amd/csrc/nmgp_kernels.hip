@@ -353,6 +353,7 @@ void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, doubl
 // mirror the lower triangle into the upper one (column-major n x n)
 __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld, int n) {
     __shared__ double tile[64][65];
+    A += (size_t)blockIdx.z * ld * n;
     const int bi = blockIdx.x, bj = blockIdx.y;   // tile row / col, bi >= bj handled
     if (bi < bj) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld
     }
 }
 
-void fill_lower_to_full(hipStream_t s, double* A, int ld, int n) {
-    hipLaunchKernelGGL(k_sym_fill, dim3(cdiv(n, 64), cdiv(n, 64)), dim3(256), 0, s, A, ld, n);
+void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch) {
+    hipLaunchKernelGGL(k_sym_fill, dim3(cdiv(n, 64), cdiv(n, 64), batch), dim3(256), 0, s, A, ld, n);
 }
 
 // y[m N + i] = Y[i, m]  (logpos.py:338)
@@ -440,6 +441,14 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j0 = J * TJ;
     const size_t Ns = (size_t)N;
+    {   // blockIdx.z = chain of the batch
+        const size_t z = blockIdx.z;
+        ell += z * Ns;
+        Lv += z * Ns * T;
+        alpha += z * Ns * M;
+        Sinv += z * (size_t)ld * (Ns * M);
+        part += z * (size_t)gridDim.y * Ns * (T + 1);
+    }
     if (tid < TJ) {
         int j = j0 + tid;
         sx[tid] = (j < N) ? x[j] : 0.0;
@@ -513,8 +522,8 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
 
 // ssign = +1 when Sinv holds Sigma^-1 (rocSOLVER potri), -1 when it holds -Sigma^-1 (C -= X X^T of the custom path)
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part, double ssign) {
-    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+                const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);      // batched: Sinv matrices are ld x (N M) apart (ld == N M there)
 #define NMGP_ADJ(MM) \
     hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign)
     switch (M) {
@@ -537,6 +546,9 @@ __global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__
                                                        const double* __restrict__ Sinv, int ld, int n,
                                                        double* __restrict__ out, double ssign) {
     __shared__ double sh[16];
+    alpha += (size_t)blockIdx.x * n;
+    Sinv += (size_t)blockIdx.x * ld * n;
+    out += (size_t)blockIdx.x * 2;
     double a = 0.0, d = 0.0;
     for (int r = threadIdx.x; r < n; r += blockDim.x) {
         a += alpha[r] * alpha[r];
@@ -550,8 +562,9 @@ __global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__
     }
 }
 
-void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out, double ssign) {
-    hipLaunchKernelGGL(k_trace_terms, dim3(1), dim3(1024), 0, s, alpha, Sinv, ld, n, out, ssign);
+void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out, double ssign,
+                 int batch) {
+    hipLaunchKernelGGL(k_trace_terms, dim3(batch), dim3(1024), 0, s, alpha, Sinv, ld, n, out, ssign);
 }
 
 // Assemble d NegLog / d pars from the adjoint partials, the prior solves and the scalar terms.
@@ -565,6 +578,15 @@ __global__ __launch_bounds__(256) void k_svc_grad_final(const double* __restrict
                                                          double* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t P = (size_t)N * (1 + T) + 1;
+    {   // blockIdx.y = chain of the batch
+        const size_t z = blockIdx.y;
+        part += z * (size_t)NJ * N * (T + 1);
+        Lv += z * (size_t)N * T;
+        R2 += z * (size_t)(1 + T) * ldR;
+        pars += z * P;
+        tr += z * 2;
+        grad += z * P;
+    }
     if (i == 0) {
         const double tse = pars[P - 1];
         const double sigma2 = exp(tse);
@@ -593,10 +615,11 @@ __global__ __launch_bounds__(256) void k_svc_grad_final(const double* __restrict
 }
 
 void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
-                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad) {
+                    int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad,
+                    int batch) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_grad_final, dim3(cdiv(N, 256)), dim3(256), 0, s, part, NJ, N, M, T, Lv, R2, ldR, pars, tr,
-                       a, b, prior, grad);
+    hipLaunchKernelGGL(k_svc_grad_final, dim3(cdiv(N, 256), batch), dim3(256), 0, s, part, NJ, N, M, T, Lv, R2, ldR,
+                       pars, tr, a, b, prior, grad);
 }
 
 // Scalar epilogue of the nonseparable objective (logpos.py:354-376 + distributions.py:22,126-134).

@@ -33,6 +33,7 @@ __device__ inline double block_sum_e(double v, double* sh /*[16]*/) {
 // HBM-bound: K is streamed exactly once, y (m2 * n2 doubles) stays in L2.
 // ---------------------------------------------------------------------------------------------
 #define KMV_CH 8
+template <bool VEC2>
 __global__ __launch_bounds__(256) void k_kron_mv(const double* __restrict__ K, int n1, int n2,
                                                   const double* __restrict__ y, const double* __restrict__ B, int m1,
                                                   int m2, double* __restrict__ out) {
@@ -45,11 +46,45 @@ __global__ __launch_bounds__(256) void k_kron_mv(const double* __restrict__ K, i
         double acc[KMV_CH];
 #pragma unroll
         for (int b = 0; b < KMV_CH; ++b) acc[b] = 0.0;
-        for (int c = lane; c < n2; c += 64) {
-            const double kv = row[c];
+        if (VEC2) {
+            // 16 bytes per lane, four independent row segments in flight per lane (1 KiB per wave instruction)
+            const int n2h = n2 >> 1;
+            const double2* row2 = reinterpret_cast<const double2*>(row);
+            int c = lane;
+            for (; c + 192 < n2h; c += 256) {
+                double2 kv[4];
 #pragma unroll
-            for (int b = 0; b < KMV_CH; ++b)
-                if (b0 + b < m2) acc[b] = fma(kv, y[(size_t)(b0 + b) * n2 + c], acc[b]);
+                for (int u = 0; u < 4; ++u) kv[u] = row2[c + 64 * u];
+#pragma unroll
+                for (int b = 0; b < KMV_CH; ++b) {
+                    if (b0 + b < m2) {
+                        const double2* y2 = reinterpret_cast<const double2*>(y + (size_t)(b0 + b) * n2);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double2 yv = y2[c + 64 * u];
+                            acc[b] = fma(kv[u].x, yv.x, acc[b]);
+                            acc[b] = fma(kv[u].y, yv.y, acc[b]);
+                        }
+                    }
+                }
+            }
+            for (; c < n2h; c += 64) {
+                const double2 kv = row2[c];
+#pragma unroll
+                for (int b = 0; b < KMV_CH; ++b)
+                    if (b0 + b < m2) {
+                        const double2 yv = reinterpret_cast<const double2*>(y + (size_t)(b0 + b) * n2)[c];
+                        acc[b] = fma(kv.x, yv.x, acc[b]);
+                        acc[b] = fma(kv.y, yv.y, acc[b]);
+                    }
+            }
+        } else {
+            for (int c = lane; c < n2; c += 64) {
+                const double kv = row[c];
+#pragma unroll
+                for (int b = 0; b < KMV_CH; ++b)
+                    if (b0 + b < m2) acc[b] = fma(kv, y[(size_t)(b0 + b) * n2 + c], acc[b]);
+            }
         }
 #pragma unroll
         for (int b = 0; b < KMV_CH; ++b) {
@@ -69,7 +104,11 @@ __global__ __launch_bounds__(256) void k_kron_mv(const double* __restrict__ K, i
 int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, const double* B, int m1, int m2,
             double* out) {
     if (m2 > 64) return NMGP_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_kron_mv, dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
+    const bool vec2 = (n2 % 2 == 0) && (((size_t)K | (size_t)y) % 16 == 0);
+    if (vec2)
+        hipLaunchKernelGGL((k_kron_mv<true>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
+    else
+        hipLaunchKernelGGL((k_kron_mv<false>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
     return 0;
 }
 

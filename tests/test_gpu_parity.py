@@ -378,9 +378,15 @@ def test_batched_chains_match_single_evaluations(ctx):
         out, status = ctx.svc_batch_fetch()
         assert np.all(status == 0)
         assert relerr(out[0], g["out"]) < VAL_TOL and relerr(out[0][1], g["out"][1]) < LIK_TOL
+        ctx.svc_batch_eval(g["hyper"], True, want_grad=True)
+        outg, statusg = ctx.svc_batch_fetch()
+        grads = ctx.svc_batch_fetch_grad()
+        assert np.all(statusg == 0) and relerr(outg, out) < 1e-9
+        assert vec_relerr(grads[0], g["grad"]) < GRAD_TOL
         for k in range(B):
-            single, _ = ctx.logpos_svc(pars[k], g["hyper"], prior=True)
+            single, gsingle = ctx.logpos_svc(pars[k], g["hyper"], prior=True, want_grad=True)
             assert relerr(out[k][1], single[1]) < 1e-12 and relerr(out[k], single) < 1e-9, (name, k, out[k], single)
+            assert vec_relerr(grads[k], gsingle) < 1e-9
     g = golden("svc_rngfree_N64_M3")
     ctx.set_data(g["x"], g["Y"])
     ctx.svc_batch_alloc(3)
