@@ -161,3 +161,68 @@ class HMCSampler:
 def sampler(**kw):
     """Alias with the reference's constructor spelling: ``HMC_Sampler.HMC_sampler.sampler(...)``."""
     return HMCSampler(**kw)
+
+
+class BatchedHMC:
+    """B independent HMC chains of one subject advanced in lock-step on the GPU.
+
+    Every leapfrog step evaluates the potential and its gradient for ALL chains with one batched launch sequence
+    (``nmgp_svc_batch_eval(want_grad=1)``): the chains are the reference's embarrassingly-parallel unit
+    (one process each there, ``Nonseparable_model_mpisim.py:305-306``); here they share the GPU's launch latency.
+    Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
+    """
+
+    def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None):
+        from . import _lib
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.q = np.array(init_positions, dtype=np.float64, copy=True)
+        if self.q.ndim != 2:
+            raise ValueError("init_positions must be [B, P]")
+        self.B, self.P = self.q.shape
+        keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
+        self.hyper = np.array([float(hyper_pars[k]) for k in keys])
+        self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
+        self.ctx.svc_batch_alloc(self.B)
+        self.eps = float(step_size)
+        self.L = int(num_steps_in_leap)
+        self.rngs = [np.random.default_rng(None if seed is None else seed + b) for b in range(self.B)]
+
+    def potential_and_grad(self, q):
+        """U [B] and dU/dq [B, P]; a chain whose covariance is not positive definite gets U = inf."""
+        self.ctx.svc_batch_set_pars(q)
+        self.ctx.svc_batch_eval(self.hyper, True, want_grad=True)
+        out, status = self.ctx.svc_batch_fetch()
+        g = self.ctx.svc_batch_fetch_grad()
+        U = out[:, 0].copy()
+        bad = status != 0
+        U[bad] = np.inf
+        g[bad] = 0.0
+        return U, g
+
+    def run(self, sample_size):
+        B, P = self.B, self.P
+        samples = np.zeros((sample_size, B, P))
+        U, g = self.potential_and_grad(self.q)
+        accepted = np.zeros(B)
+        energy_err = np.zeros((sample_size, B))
+        for it in range(sample_size):
+            p0 = np.stack([r.standard_normal(P) for r in self.rngs])
+            H0 = U + 0.5 * (p0 * p0).sum(1)
+            q1 = self.q.copy()
+            p1 = p0 - 0.5 * self.eps * g
+            U1, g1 = U, g
+            for step in range(self.L):
+                q1 = q1 + self.eps * p1
+                U1, g1 = self.potential_and_grad(q1)
+                p1 = p1 - (self.eps if step < self.L - 1 else 0.5 * self.eps) * g1
+            H1 = U1 + 0.5 * (p1 * p1).sum(1)
+            dH = H1 - H0
+            u = np.array([np.log(r.random()) for r in self.rngs])
+            acc = np.isfinite(dH) & (u < -dH)
+            self.q[acc] = q1[acc]
+            U = np.where(acc, U1, U)
+            g = np.where(acc[:, None], g1, g)
+            accepted += acc
+            energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
+            samples[it] = self.q
+        return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
