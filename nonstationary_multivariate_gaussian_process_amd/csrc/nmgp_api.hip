@@ -146,6 +146,7 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     }
     HIP_TRY(c, hipSetDevice(device));
     if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);
+    if (const char* e = std::getenv("NMGP_SEP")) c->sep_algo = (std::strcmp(e, "eig") == 0) ? 0 : 1;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
@@ -292,7 +293,7 @@ int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
 }
 
 // events for the look-ahead factorisation (created once, reused by every evaluation)
-static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
+hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n) {
     if (!c->chol_lookahead) return nullptr;
     const size_t need = 2 * (size_t)((n + c->chol_nb1 - 1) / c->chol_nb1) + 3;
     while (c->chol_ev.size() < need) {
@@ -305,7 +306,7 @@ static hipEvent_t* chol_events(nmgp_ctx* c, int n) {
 
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
     if (c->chol_algo == 1 && (ld % 2 == 0)) {
-        potrf_lower(c->stream, c->stream2, chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0);
+        potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0);
         return 0;
     }
     if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
@@ -356,7 +357,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
             // with gradient: a zero pad row (keeps the next block at an even offset) and n identity rows -> X = L^-T
             if (want_grad) identity_rows(s, c->d_S, ld, n + 1, n, xpad);
             // row n becomes z = L^-1 y
-            potrf_lower(s, c->stream2, chol_events(c, n), c->d_S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0,
+            potrf_lower(s, c->stream2, nmgp_chol_events(c, n), c->d_S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0,
                         c->chol_nb1, c->d_info, 1, 0, 0);
         }
         {
@@ -604,7 +605,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         StageScope sp(c, NMGP_STAGE_CHOL);
         set_row(s, S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
         if (want_grad) identity_rows(s, S, ld, n + 1, n, xpad, B, bs);
-        potrf_lower(s, c->stream2, chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
                     c->b_info, B, bs, 1);
     }
     {
@@ -751,7 +752,7 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     if (algo == 1) {
         StageScope sp(c, NMGP_STAGE_CHOL);
         if (rhs) set_row(s, dA, (int)ld, n, dv, n, 1, 0, 0);
-        potrf_lower(s, c->stream2, chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
         if (rhs) get_row(s, dA, (int)ld, n, dv + n, n, 1, 0, 0);
     } else {
         StageScope sp(c, NMGP_STAGE_CHOL);

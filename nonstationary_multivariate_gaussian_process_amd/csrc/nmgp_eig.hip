@@ -258,6 +258,133 @@ int prior_solve(nmgp_ctx* c, PriorFactor* pf, double* R, int ncol, double* R2) {
     return 0;
 }
 
+// ---- Cholesky formulation of the Kronecker likelihood -------------------------------------------------------
+// loglik of N(0, B kron K + sigma2 I) as M independent N x N factorisations S_p = wB[p] K + sigma2 I (one batch of the
+// blocked Cholesky; no eigendecomposition of K).  K's lower triangle must be in c->d_K (ld = N) and survives.
+// With want_grad the same adjoint quantities as kron_adjoint are produced.
+struct CholKron {
+    double* alpha = nullptr;   // [M, N]  S_p^-1 yt_p   (== U of the adjoint kernel, column-major [N, M])
+    double* Cneg = nullptr;    // [M] x (N x N): -S_p^-1
+    std::vector<double> tr, tk, aa;   // per block: tr S_p^-1, <S_p^-1, K>, ||alpha_p||^2
+};
+
+int kron_chol_loglik(nmgp_ctx* c, EigWork& w, double sigma2, bool want_grad, double* loglik, CholKron* ck) {
+    const int N = w.N, M = w.M;
+    hipStream_t s = c->stream;
+    const int xpad = (N + 1) & 1, xoff = N + 1 + xpad;
+    const int ld = want_grad ? (int)((((size_t)2 * N + 2 + 15) / 16) * 16) : (int)((((size_t)N + 1 + 15) / 16) * 16);
+    const long long bs = (long long)ld * N;
+    double *S, *sm;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)M * bs, &S));
+    NMGP_TRY(nmgp_scratch_get(c, SL_A, (size_t)3 * M * N + 64 + (size_t)M * 16, &sm));
+    double *yt = sm, *z = sm + (size_t)M * N, *alpha = z + (size_t)M * N, *red = alpha + (size_t)M * N;
+    int* info = reinterpret_cast<int*>(red + (size_t)M * 4);
+    HIP_TRY(c, hipMemsetAsync(info, 0, (size_t)M * sizeof(int), s));
+    {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        rotate_y(s, c->d_Y, w.VB, N, M, yt);                          // yt_p = (V_B^T kron I) y
+        sep_blocks(s, c->d_K, w.wB, w.sig2, N, M, S, ld, bs);
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_CHOL);
+        set_row(s, S, ld, N, yt, N, M, bs, N);
+        if (want_grad) identity_rows(s, S, ld, N + 1, N, xpad, M, bs);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, N), S, ld, N, want_grad ? 1 + xpad : 1, want_grad ? N : 0,
+                    c->chol_nb1, info, M, bs, 1);
+        get_row(s, S, ld, N, z, N, M, bs, N);
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_REDUCE);
+        chol_logdet_quad(s, S, ld, N, z, red, red + 1, M, bs, 4);
+    }
+    std::vector<double> hr((size_t)M * 4);
+    std::vector<int> hi(M);
+    HIP_TRY(c, hipMemcpyAsync(hr.data(), red, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int p = 0; p < M; ++p)
+        if (hi[p] != 0)
+            return nmgp_fail(c, hi[p], "block %d of the separable covariance is not positive definite (leading minor %d)",
+                             p, hi[p]);
+    double ll = 0.0;
+    for (int p = 0; p < M; ++p) ll += -0.5 * hr[(size_t)p * 4] - 0.5 * hr[(size_t)p * 4 + 1];
+    *loglik = ll;
+    if (!want_grad) return 0;
+    double* Cneg;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, (size_t)M * N * N, &Cneg));
+    {
+        NmgpStage sp(c, NMGP_STAGE_INVERSE);
+        const double one = 1.0, zero = 0.0;
+        BLAS_TRY(c, rocblas_dgemv_strided_batched(c->blas, rocblas_operation_none, N, N, &one, S + xoff, ld, bs, z, 1, N,
+                                                  &zero, alpha, 1, N, M));                       // alpha_p = X_p z_p
+        HIP_TRY(c, hipMemsetAsync(Cneg, 0, (size_t)M * N * N * sizeof(double), s));
+        syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, M, bs, (long long)N * N, 1);              // -S_p^-1
+    }
+    double* part;
+    NMGP_TRY(nmgp_scratch_get(c, SL_PART, (size_t)M * 128 * 3 + 8, &part));
+    const int G = sep_traces(s, Cneg, c->d_K, alpha, N, M, part);
+    std::vector<double> hp((size_t)M * G * 3);
+    HIP_TRY(c, hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    ck->tr.assign(M, 0.0);
+    ck->tk.assign(M, 0.0);
+    ck->aa.assign(M, 0.0);
+    for (int p = 0; p < M; ++p)
+        for (int g = 0; g < G; ++g) {
+            ck->tr[p] += hp[((size_t)p * G + g) * 3];
+            ck->tk[p] += hp[((size_t)p * G + g) * 3 + 1];
+            ck->aa[p] += hp[((size_t)p * G + g) * 3 + 2];
+        }
+    ck->alpha = alpha;
+    ck->Cneg = Cneg;
+    return 0;
+}
+
+// Adjoint for the Cholesky formulation: per-location gradients d_g ([2N] = g_tl | g_ts), dB (host), d loglik/d sigma2.
+int kron_chol_adjoint(nmgp_ctx* c, EigWork& w, CholKron& ck, const double* d_ell, const double* d_sig, double* d_g,
+                      std::vector<double>& dB, double* dsigma2) {
+    const int N = w.N, M = w.M;
+    hipStream_t s = c->stream;
+    const double one = 1.0, zero = 0.0;
+    double *C, *W, *part;
+    NMGP_TRY(nmgp_scratch_get(c, SL_K3, (size_t)N * N, &C));
+    NMGP_TRY(nmgp_scratch_get(c, SL_U, (size_t)N * M + (size_t)M * M, &W));
+    double* Xi = W + (size_t)N * M;
+    const int NJ = (N + 63) / 64;
+    NMGP_TRY(nmgp_scratch_get(c, SL_PART, (size_t)NJ * N * 2 + (size_t)M * 128 * 3 + 8, &part));
+    {
+        NmgpStage sp(c, NMGP_STAGE_ADJOINT);
+        weighted_sum_lower(s, ck.Cneg, w.wB, N, M, C);                 // C = sum_p wB[p] S_p^-1 (lower)
+        fill_lower_to_full(s, C, N, N);
+        sep_adjoint(s, c->d_x, d_ell, d_sig, ck.alpha, w.wB, M, C, N, part);
+        sep_grad_sum(s, part, NJ, N, d_g);
+        // Xi' = U^T (K U): the M x M quadratic forms alpha_p^T K alpha_p'
+        BLAS_TRY(c, rocblas_dsymm(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, c->d_K, N, ck.alpha, N, &zero,
+                                  W, N));
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, ck.alpha, N,
+                                  W, N, &zero, Xi, M));
+    }
+    std::vector<double> hx((size_t)M * M);
+    HIP_TRY(c, hipMemcpyAsync(hx.data(), Xi, hx.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    // d loglik / dB = V_B Xi V_B^T,  Xi[p,p'] = 1/2 (alpha_p^T K alpha_p' - d_pp' <S_p^-1, K>)
+    std::vector<double> Xs((size_t)M * M);
+    for (int p = 0; p < M; ++p)
+        for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (hx[(size_t)q * M + p] - (p == q ? ck.tk[p] : 0.0));
+    dB.assign((size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < M; ++j) {
+            double acc = 0.0;
+            for (int p = 0; p < M; ++p)
+                for (int q = 0; q < M; ++q) acc += w.h_VB[(size_t)i * M + p] * Xs[(size_t)p * M + q] * w.h_VB[(size_t)j * M + q];
+            dB[(size_t)i * M + j] = acc;
+        }
+    double ds = 0.0;
+    for (int p = 0; p < M; ++p) ds += 0.5 * (ck.aa[p] - ck.tr[p]);
+    *dsigma2 = ds;
+    return 0;
+}
+
 int require_data(nmgp_ctx* c) {
     if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
     return 0;
@@ -294,7 +421,11 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
     }
     double hs[4], loglik;
-    NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    CholKron ck;
+    if (c->sep_algo == 1)
+        NMGP_TRY(kron_chol_loglik(c, w, sigma2, grad != nullptr, &loglik, &ck));
+    else
+        NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
     // GP priors on tilde_l and tilde_sigma (logpos.py:271-281)
     PriorFactor *pl = nullptr, *ps = nullptr;
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
@@ -333,7 +464,10 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         NMGP_TRY(nmgp_scratch_get(c, SL_G, (size_t)2 * N, &d_g));
         std::vector<double> dB, g_uL;
         double ds;
-        NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
+        if (c->sep_algo == 1)
+            NMGP_TRY(kron_chol_adjoint(c, w, ck, c->d_ell, c->d_sig, d_g, dB, &ds));
+        else
+            NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
         dB_to_guL(dB, w.h_L, M, g_uL);
         std::vector<double> hg((size_t)2 * N), hr((size_t)2 * N, 0.0);
         HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -379,7 +513,11 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:429
     }
     double hs[4], loglik;
-    NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    CholKron ck;
+    if (c->sep_algo == 1)
+        NMGP_TRY(kron_chol_loglik(c, w, sigma2, grad != nullptr, &loglik, &ck));
+    else
+        NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
     double dl = 0.0, lp_l = 0.0, lp_uL = 0.0, lp_s2 = 0.0;
     std::vector<double> g_uL_prior(T, 0.0);
     // the reference only evaluates the prior terms when Prior is true (logpos.py:445-458)
@@ -395,7 +533,10 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
         NMGP_TRY(nmgp_scratch_get(c, SL_G, (size_t)2 * N + 8, &d_g));
         std::vector<double> dB, g_uL;
         double ds;
-        NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
+        if (c->sep_algo == 1)
+            NMGP_TRY(kron_chol_adjoint(c, w, ck, c->d_ell, c->d_sig, d_g, dB, &ds));
+        else
+            NMGP_TRY(kron_adjoint(c, w, c->d_ell, c->d_sig, hs, d_g, dB, &ds));
         dB_to_guL(dB, w.h_L, M, g_uL);
         std::vector<double> hg((size_t)2 * N);
         HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));

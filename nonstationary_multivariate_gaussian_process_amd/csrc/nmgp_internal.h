@@ -46,6 +46,7 @@ struct nmgp_ctx {
     hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation
     std::vector<hipEvent_t> chol_ev;          // events ordering the two streams
     int chol_lookahead = 1;
+    int sep_algo = 1;                         // separable/stationary likelihood: 1 = M batched Cholesky blocks, 0 = dsyevd
     rocblas_handle blas = nullptr;
     std::string err;
 
@@ -123,6 +124,7 @@ int nmgp_ensure_S(nmgp_ctx* c);
 // Cholesky of the n x n lower triangle (custom gfx950 factorisation or rocSOLVER, per ctx->chol_algo); `extra` rows
 // below the matrix are carried along by the custom path only (must be 0 for rocSOLVER).
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info);
+hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n);
 struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream
     nmgp_ctx* c; int stage; hipEvent_t e0 = nullptr, e1 = nullptr;
     NmgpStage(nmgp_ctx* ctx, int st);
@@ -226,6 +228,11 @@ void sep_predict(hipStream_t st, const double* Cq, const double* a, const double
 void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_s, double* tl_star, double* ts_star,
               double* kss);
 void add_diag(hipStream_t s, double* A, int ld, int n, double v);
+void rotate_y(hipStream_t s, const double* Y, const double* VB, int N, int M, double* yt);
+void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* sigma2p, int N, int M, double* out,
+                int ldo, long long bstride);
+int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double* alpha, int N, int M, double* out);
+void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride = -1, int ktri = 0);

@@ -549,6 +549,98 @@ void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_
     hipLaunchKernelGGL(k_sep_star, dim3(cdiv(S, 256)), dim3(256), 0, st, proj, S, mu_l, mu_s, tl_star, ts_star, kss);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Separable likelihood without an eigendecomposition of K_x: with B = V_B diag(wB) V_B^T (M x M, host),
+//   B kron K + sigma2 I = (V_B kron I) blockdiag_p( wB[p] K + sigma2 I ) (V_B^T kron I),
+// so the MN x MN problem is M independent N x N Cholesky factorisations (one batch of the blocked factorisation).
+// ---------------------------------------------------------------------------------------------
+// yt[p N + i] = sum_m Y[i, m] VB[m, p]      (Y row-major [N, M], VB row-major [M, M])
+__global__ void k_rotate_y(const double* __restrict__ Y, const double* __restrict__ VB, int N, int M,
+                           double* __restrict__ yt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = blockIdx.y;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s += Y[(size_t)i * M + m] * VB[m * M + p];
+    yt[(size_t)p * N + i] = s;
+}
+void rotate_y(hipStream_t s, const double* Y, const double* VB, int N, int M, double* yt) {
+    hipLaunchKernelGGL(k_rotate_y, dim3(cdiv(N, 256), M), dim3(256), 0, s, Y, VB, N, M, yt);
+}
+
+// out_p[i, j] = wB[p] K[i, j] + sigma2 d_ij   (lower triangle, column-major; K: ld = N, out: leading dimension ldo)
+__global__ __launch_bounds__(256) void k_sep_blocks(const double* __restrict__ K, const double* __restrict__ wB,
+                                                     const double* __restrict__ sigma2p, int N,
+                                                     double* __restrict__ out, int ldo, long long bstride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= N || i < j) return;
+    const double w = wB[blockIdx.z];
+    double v = w * K[(size_t)j * N + i];
+    if (i == j) v += sigma2p[0];
+    out[(size_t)blockIdx.z * bstride + (size_t)j * ldo + i] = v;
+}
+void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* sigma2p, int N, int M, double* out,
+                int ldo, long long bstride) {
+    hipLaunchKernelGGL(k_sep_blocks, dim3(cdiv(N, 256), N, M), dim3(256), 0, s, K, wB, sigma2p, N, out, ldo, bstride);
+}
+
+// per block p (Cneg_p = -S_p^-1, lower, ld = N) partial sums over the columns j = blockIdx.y, +gridDim.y, ...:
+//   out[(p G + g) 3 + 0] += tr S_p^-1,  [.. + 1] += <S_p^-1, K> (full symmetric inner product from the lower triangles),
+//   [.. + 2] += ||alpha_p||^2 (chunk g = 0 only).  The host adds the G partials (deterministic order).
+#define SEP_TR_G 128
+__global__ __launch_bounds__(256) void k_sep_traces(const double* __restrict__ Cneg, const double* __restrict__ K,
+                                                     const double* __restrict__ alpha, int N,
+                                                     double* __restrict__ out) {
+    __shared__ double sh[16];
+    const int p = blockIdx.x, g = blockIdx.y;
+    const double* C = Cneg + (size_t)p * N * N;
+    double tr = 0.0, tk = 0.0, aa = 0.0;
+    for (int j = g; j < N; j += SEP_TR_G) {
+        for (int i = j + threadIdx.x; i < N; i += blockDim.x) {
+            const double c = -C[(size_t)j * N + i];
+            const double k = K[(size_t)j * N + i];
+            if (i == j) {
+                tr += c;
+                tk += c * k;
+            } else {
+                tk += 2.0 * c * k;
+            }
+        }
+    }
+    if (g == 0)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) aa += alpha[(size_t)p * N + i] * alpha[(size_t)p * N + i];
+    tr = block_sum_e(tr, sh);
+    tk = block_sum_e(tk, sh);
+    aa = block_sum_e(aa, sh);
+    if (threadIdx.x == 0) {
+        double* o = out + ((size_t)p * SEP_TR_G + g) * 3;
+        o[0] = tr;
+        o[1] = tk;
+        o[2] = aa;
+    }
+}
+int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double* alpha, int N, int M, double* out) {
+    hipLaunchKernelGGL(k_sep_traces, dim3(M, SEP_TR_G), dim3(256), 0, s, Cneg, K, alpha, N, out);
+    return SEP_TR_G;
+}
+
+// C[i, j] = - sum_p wB[p] Cneg_p[i, j]  (lower triangle; = sum_p wB[p] S_p^-1)
+__global__ __launch_bounds__(256) void k_weighted_sum_lower(const double* __restrict__ Cneg,
+                                                             const double* __restrict__ wB, int N, int M,
+                                                             double* __restrict__ C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= N || i < j) return;
+    double s = 0.0;
+    for (int p = 0; p < M; ++p) s += wB[p] * Cneg[(size_t)p * N * N + (size_t)j * N + i];
+    C[(size_t)j * N + i] = -s;
+}
+void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C) {
+    hipLaunchKernelGGL(k_weighted_sum_lower, dim3(cdiv(N, 256), N), dim3(256), 0, s, Cneg, wB, N, M, C);
+}
+
 // A[r, r] += v  (n x n, leading dimension ld)
 __global__ void k_add_diag(double* __restrict__ A, int ld, int n, double v) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -397,3 +397,27 @@ def test_batched_chains_match_single_evaluations(ctx):
     out, status = ctx.svc_batch_fetch()
     assert status[0] == 0 and status[2] == 0 and status[1] != 0
     assert np.all(np.isnan(out[1])) and relerr(out[0], g["out"]) < VAL_TOL and np.array_equal(out[0], out[2])
+
+
+def test_separable_cholesky_and_eigen_formulations_agree():
+    """The default separable/stationary path factors M blocks wB[p] K + sigma2 I with the batched Cholesky; the
+    reference's eigen-trick formulation (distributions.py:26-52) stays selectable and must give the same numbers."""
+    import os
+    from nonstationary_multivariate_gaussian_process_amd import _lib
+    res = {}
+    for algo in ("chol", "eig"):
+        os.environ["NMGP_SEP"] = algo
+        try:
+            c = _lib.Context(0)
+        finally:
+            os.environ.pop("NMGP_SEP", None)
+        for name in ("sep_sim_N512_M5", "sta_sim_N128_M2"):
+            g = golden(name)
+            c.set_data(g["x"], g["Y"])
+            fn = c.logpos_sep if name.startswith("sep") else c.logpos_sta
+            res[(algo, name)] = fn(g["pars"], g["hyper"], True, True)
+        c.close()
+    for name in ("sep_sim_N512_M5", "sta_sim_N128_M2"):
+        a, b = res[("chol", name)], res[("eig", name)]
+        assert relerr(a[0][1], b[0][1]) < 1e-9 and relerr(a[0], b[0]) < 1e-9
+        assert vec_relerr(a[1], b[1]) < 1e-7
