@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--chains", type=int, default=16,
                     help="independent MCMC chains of the subject evaluated per step through the batched entry "
                          "(nmgp_svc_batch_*): one launch sequence covers all chains")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the chains into this many groups, each a batched context on its own pair of HIP streams, "
+                         "so that one group's latency-bound panel steps overlap another group's MFMA updates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=3)
     a = ap.parse_args()
@@ -89,18 +92,30 @@ def main():
     ctx.svc_set_pars(pars)
     want_grad = bool(a.grad)
     B = max(1, a.chains)
+    G = max(1, min(a.groups, B))
+    ctxs = [ctx] + [_lib.Context(local_rank) for _ in range(G - 1)]
     if B > 1:
-        ctx.svc_batch_alloc(B)
         # chain b starts from its own smooth perturbation of the generating parameters
-        ctx.svc_batch_set_pars(np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * b) for b in range(B)]))
+        allp = np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * b) for b in range(B)])
+        sizes = [B // G + (1 if g < B % G else 0) for g in range(G)]
+        off = 0
+        for cg, sz in zip(ctxs, sizes):
+            cg.set_data(d["x"], d["Y"])
+            cg.svc_batch_alloc(sz)
+            cg.svc_batch_set_pars(allp[off:off + sz])
+            off += sz
 
     def step():
         if B > 1:
-            ctx.svc_batch_eval(hv, True, want_grad)
-            o, st = ctx.svc_batch_fetch()
-            if st.any():
-                raise RuntimeError("chain failed: %s" % st)
-            return o[0]
+            for cg in ctxs:
+                cg.svc_batch_eval(hv, True, want_grad)
+            first = None
+            for cg in ctxs:
+                o, st = cg.svc_batch_fetch()
+                if st.any():
+                    raise RuntimeError("chain failed: %s" % st)
+                first = o[0] if first is None else first
+            return first
         ctx.svc_eval_resident(hv, True, want_grad)
         return ctx.svc_fetch(False)[0]
 
@@ -111,7 +126,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        for cg in ctxs:
+            cg.sync()
 
     ctx.profile_enable(True)
     ctx.profile_reset()
@@ -152,7 +168,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "nonseparable GP nlogpos_obj_SVC %s, D=%d, N=%d (MN=%d), %d independent chain(s) per "
                                    "GPU evaluated per step" % ("value+gradient" if want_grad else "value", M, N, n, B),
-                       "chains_per_gpu": B,
+                       "chains_per_gpu": B, "stream_groups": G,
                        "stage_ms": stage_ms, "neglog_rank0": float(out[0]),
                        "chains_ok": int(chain_stats[0]), "sum_neglog_all_chains": float(chain_stats[3]),
                        "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,

@@ -29,15 +29,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define SY_BK 16
 #define SY_LD (SY_BM + 16)
 
-__device__ inline double2 load2_guard(const double* __restrict__ p, int r, int rows) {
-    double2 v;
-    if (r + 1 < rows) {
-        v = *reinterpret_cast<const double2*>(p);
-    } else {
-        v.x = (r < rows) ? p[0] : 0.0;
-        v.y = 0.0;
-    }
-    return v;
+// The k-panel prefetch must stay asynchronous: gload() only ISSUES 16-byte loads from clamped (always valid)
+// addresses; the zeroing of out-of-range rows / k-columns is applied by sstore(), right before the LDS write, i.e.
+// after the MFMAs of the current panel.  Touching the loaded value earlier (a select, or a vector/scalar load pair
+// under exec masks) makes hipcc place `s_waitcnt vmcnt(0)` directly behind each load: 8 exposed L2 round trips per
+// k-step, which capped this kernel at 60 % MFMA utilisation.
+__device__ __forceinline__ int clamp_row_pair(int r, int rows) {
+    int rc = r < rows - 1 ? r : rows - 2;
+    return rc < 0 ? 0 : rc;
 }
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
@@ -57,26 +56,35 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     const int rp = tid & 63, cg = tid >> 6;
     double2 ra[4], rb[4];
 
+    const int ri = row0 + 2 * rp, rj = col0 + 2 * rp;
+    const int ric = clamp_row_pair(ri, mrows), rjc = clamp_row_pair(rj, mrows);
+    const bool ix = ri < mrows, iy = ri + 1 < mrows, jx = rj < mrows, jy = rj + 1 < mrows;
+    // the last row of an odd-height panel sits at an even index with no partner: its clamped pair starts one row
+    // earlier, so the wanted value arrives in .y
+    const bool ish = ix && (ric != ri), jsh = jx && (rjc != rj);
     auto gload = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int kc = k0 + cg + 4 * q;
-            const int ri = row0 + 2 * rp, rj = col0 + 2 * rp;
-            if (kc < K) {
-                ra[q] = load2_guard(A + (size_t)kc * lda + ri, ri, mrows);
-                if (!diag) rb[q] = load2_guard(A + (size_t)kc * lda + rj, rj, mrows);
-            } else {
-                ra[q] = make_double2(0.0, 0.0);
-                rb[q] = make_double2(0.0, 0.0);
-            }
+            const double* colp = A + (size_t)(kc < K ? kc : K - 1) * lda;
+            ra[q] = *reinterpret_cast<const double2*>(colp + ric);
+            if (!diag) rb[q] = *reinterpret_cast<const double2*>(colp + rjc);
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int kc = cg + 4 * q;
-            *reinterpret_cast<double2*>(&sA[buf][kc * SY_LD + 2 * rp]) = ra[q];
-            if (!diag) *reinterpret_cast<double2*>(&sB[buf][kc * SY_LD + 2 * rp]) = rb[q];
+            const int kl = cg + 4 * q;
+            const bool kin = (k0 + kl) < K;
+            double2 va, vb;
+            va.x = (kin && ix) ? (ish ? ra[q].y : ra[q].x) : 0.0;
+            va.y = (kin && iy) ? ra[q].y : 0.0;
+            *reinterpret_cast<double2*>(&sA[buf][kl * SY_LD + 2 * rp]) = va;
+            if (!diag) {
+                vb.x = (kin && jx) ? (jsh ? rb[q].y : rb[q].x) : 0.0;
+                vb.y = (kin && jy) ? rb[q].y : 0.0;
+                *reinterpret_cast<double2*>(&sB[buf][kl * SY_LD + 2 * rp]) = vb;
+            }
         }
     };
 
@@ -101,31 +109,46 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
                 const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
                 acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
-    sstore(0);
+    sstore(0, kt0 * SY_BK);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) gload((kt + 1) * SY_BK);
         if (active) {
-            const double* tA = sA[cur];
-            const double* tB = diag ? sA[cur] : sB[cur];
+            const double* tA = sA[cur] + wi * 64 + (lane & 15) + (lane >> 4) * SY_LD;
+            const double* tB = (diag ? sA[cur] : sB[cur]) + wj * 64 + (lane & 15) + (lane >> 4) * SY_LD;
+            // fragments of k-substep kk+1 are fetched from LDS while the 16 MFMAs of kk issue (software pipeline:
+            // without it every substep exposes one LDS round trip before its first MFMA)
+            double fa[4], fb[4], na[4], nb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = tA[t * 16];
+                fb[t] = -tB[t * 16];
+            }
 #pragma unroll
             for (int kk = 0; kk < SY_BK / 4; ++kk) {
-                const int k = kk * 4 + (lane >> 4);
-                double fa[4], fb[4];
+                if (kk + 1 < SY_BK / 4) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    fa[t] = tA[k * SY_LD + wi * 64 + t * 16 + (lane & 15)];
-                    fb[t] = -tB[k * SY_LD + wj * 64 + t * 16 + (lane & 15)];
+                    for (int t = 0; t < 4; ++t) {
+                        na[t] = tA[(kk + 1) * 4 * SY_LD + t * 16];
+                        nb[t] = -tB[(kk + 1) * 4 * SY_LD + t * 16];
+                    }
                 }
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti)
                         acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tj], fa[ti], acc[tj][ti], 0, 0, 0);
+                if (kk + 1 < SY_BK / 4) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        fa[t] = na[t];
+                        fb[t] = nb[t];
+                    }
+                }
             }
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
+        if (kt + 1 < nk) sstore(cur ^ 1, (kt + 1) * SY_BK);
         __syncthreads();
     }
     if (!active) return;
