@@ -40,9 +40,17 @@ __device__ __forceinline__ int clamp_row_pair(int r, int rows) {
 }
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
-__global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C,
-                                                        int ldc, int mrows, int ncols, int K, long long bstride,
-                                                        long long cstride, int ktri) {
+// NWJ = column groups of waves per 128x128 tile: 2 -> 4 waves of 64x64 (16 MFMA tiles each), 4 -> 8 waves of 64x32
+// (8 MFMA tiles each, ~110 VGPRs, so four waves per SIMD hide each other's barrier / LDS / prologue stalls).
+template <int NWJ>
+__global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __restrict__ A, int lda,
+                                                                 double* __restrict__ C, int ldc, int mrows, int ncols,
+                                                                 int K, long long bstride, long long cstride, int ktri) {
+    constexpr int NT = 128 * NWJ;          // threads
+    constexpr int CW = 128 / NWJ;          // columns per wave
+    constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
+    constexpr int NQ = 1024 / NT;          // 16-byte loads per thread per operand and k-step
+    constexpr int CGS = NT / 64;           // k-columns covered per load round
     __shared__ double sA[2][SY_BK * SY_LD];
     __shared__ double sB[2][SY_BK * SY_LD];
     const int bi = blockIdx.x, bj = blockIdx.y;
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     const int wi = w & 1, wj = w >> 1;
     const int row0 = bi * SY_BM, col0 = bj * SY_BM;
     const int rp = tid & 63, cg = tid >> 6;
-    double2 ra[4], rb[4];
+    double2 ra[NQ], rb[NQ];
 
     const int ri = row0 + 2 * rp, rj = col0 + 2 * rp;
     const int ric = clamp_row_pair(ri, mrows), rjc = clamp_row_pair(rj, mrows);
@@ -64,8 +72,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     const bool ish = ix && (ric != ri), jsh = jx && (rjc != rj);
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kc = k0 + cg + 4 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int kc = k0 + cg + CGS * q;
             const double* colp = A + (size_t)(kc < K ? kc : K - 1) * lda;
             ra[q] = *reinterpret_cast<const double2*>(colp + ric);
             if (!diag) rb[q] = *reinterpret_cast<const double2*>(colp + rjc);
@@ -73,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     };
     auto sstore = [&](int buf, int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kl = cg + 4 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int kl = cg + CGS * q;
             const bool kin = (k0 + kl) < K;
             double2 va, vb;
             va.x = (kin && ix) ? (ish ? ra[q].y : ra[q].x) : 0.0;
@@ -88,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
         }
     };
 
-    // a wave whose 64x64 sub-tile lies strictly above the diagonal has nothing to compute
-    const bool active = !(diag && wi < wj);
+    // a wave whose sub-tile lies strictly above the diagonal has nothing to compute
+    const bool active = !(diag && (wi * 64 + 63 < wj * CW));
     const int nk = (K + SY_BK - 1) / SY_BK;
     // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
     // first row contribute nothing
@@ -98,15 +106,15 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
     // the MFMA negated, so the k-loop leaves C - A A^T in registers and the epilogue is stores only.
     // D[row = (lane>>4) + 4 reg <-> j][col = lane&15 <-> i]
-    v4d acc[4][4];
+    v4d acc[TJ][4];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
-                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
+                const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
                 acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
     sstore(0, kt0 * SY_BK);
@@ -116,35 +124,32 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
         if (kt + 1 < nk) gload((kt + 1) * SY_BK);
         if (active) {
             const double* tA = sA[cur] + wi * 64 + (lane & 15) + (lane >> 4) * SY_LD;
-            const double* tB = (diag ? sA[cur] : sB[cur]) + wj * 64 + (lane & 15) + (lane >> 4) * SY_LD;
-            // fragments of k-substep kk+1 are fetched from LDS while the 16 MFMAs of kk issue (software pipeline:
+            const double* tB = (diag ? sA[cur] : sB[cur]) + wj * CW + (lane & 15) + (lane >> 4) * SY_LD;
+            // fragments of k-substep kk+1 are fetched from LDS while the MFMAs of kk issue (software pipeline:
             // without it every substep exposes one LDS round trip before its first MFMA)
-            double fa[4], fb[4], na[4], nb[4];
+            double fa[4], fb[TJ], na[4], nb[TJ];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = tA[t * 16];
-                fb[t] = -tB[t * 16];
-            }
+            for (int t = 0; t < 4; ++t) fa[t] = tA[t * 16];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) fb[t] = -tB[t * 16];
 #pragma unroll
             for (int kk = 0; kk < SY_BK / 4; ++kk) {
                 if (kk + 1 < SY_BK / 4) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        na[t] = tA[(kk + 1) * 4 * SY_LD + t * 16];
-                        nb[t] = -tB[(kk + 1) * 4 * SY_LD + t * 16];
-                    }
+                    for (int t = 0; t < 4; ++t) na[t] = tA[(kk + 1) * 4 * SY_LD + t * 16];
+#pragma unroll
+                    for (int t = 0; t < TJ; ++t) nb[t] = -tB[(kk + 1) * 4 * SY_LD + t * 16];
                 }
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj)
+                for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti)
                         acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tj], fa[ti], acc[tj][ti], 0, 0, 0);
                 if (kk + 1 < SY_BK / 4) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        fa[t] = na[t];
-                        fb[t] = nb[t];
-                    }
+                    for (int t = 0; t < 4; ++t) fa[t] = na[t];
+#pragma unroll
+                    for (int t = 0; t < TJ; ++t) fb[t] = nb[t];
                 }
             }
         }
@@ -153,23 +158,32 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lower(const double* __restrict_
     }
     if (!active) return;
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
-                const int j = col0 + wj * 64 + tj * 16 + (lane >> 4) + 4 * r;
+                const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
                 if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
             }
 }
 
+static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
+
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride, int ktri) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
+    if (g_syrk_nwj == 0) {
+        const char* e = std::getenv("NMGP_SYRK_WAVES");
+        g_syrk_nwj = (e && std::atoi(e) == 4) ? 2 : 4;
+    }
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
-    hipLaunchKernelGGL(k_syrk_lower, grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride,
-                       cstride < 0 ? bstride : cstride, ktri);
+    const long long cs = cstride < 0 ? bstride : cstride;
+    if (g_syrk_nwj == 2)
+        hipLaunchKernelGGL((k_syrk_lower<2>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+    else
+        hipLaunchKernelGGL((k_syrk_lower<4>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
 }
 
 // ---------------------------------------------------------------------------------------------
