@@ -147,8 +147,21 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     HIP_TRY(c, hipSetDevice(device));
     if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);
     if (const char* e = std::getenv("NMGP_SEP")) c->sep_algo = (std::strcmp(e, "eig") == 0) ? 0 : 1;
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        // The main stream carries the latency-bound panel steps of the factorisation, stream2 the far trailing updates
+        // that fill the chip: the main stream gets the higher priority so that its small kernels are dispatched as soon
+        // as a slot frees instead of queueing behind the update's workgroups.
+        int lo = 0, hi = 0;     // "greatest" (numerically lowest) priority is hi
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const bool prio = std::getenv("NMGP_NO_STREAM_PRIORITY") == nullptr && lo != hi;
+        if (prio) {
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        }
+    }
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
     BLAS_TRY(c, rocblas_set_stream(c->blas, c->stream));
     BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
