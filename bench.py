@@ -199,45 +199,44 @@ def max_over_ranks(elapsed, world, torch, dist):
 
 def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
     """BASELINE config 4 (Nonseparable_model_mpisim-style): subjects_per_gpu x world independent subjects, D=M, N=--N
-    (default there: 1024), subject s on rank s mod world, one context (= one HIP stream) per subject so that the
-    factorisations of different subjects overlap on the GPU.  A step = one evaluation of EVERY local subject."""
+    (default there: 1024), subject s on rank s mod world (the reference maps rank -> data file).  The rank's subjects
+    form ONE multi-subject batch (own x, Y and prior factors per batch element, nmgp_svc_batch_set_subjects): a step =
+    one evaluation of EVERY local subject by one launch sequence."""
     N, M = a.N, a.M
     n_subj = a.subjects_per_gpu * world
     mine = chains.partition(n_subj, world, rank)
     hyper = sim.HYPER_SVC_MPISIM
     hv = np.array([hyper[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a",
                                       "b")], dtype=np.float64)
-    ctxs = []
-    for s_id in mine:
-        d = sim.simulate_nonseparable(N, M, seed=s_id)       # subject s uses seed s (sim.py:361-363)
-        c = _lib.Context(local_rank)
-        c.set_data(d["x"], d["Y"])
-        c.svc_set_pars(sim.perturb(d["pars_true"], 0.05, 0.7))
-        ctxs.append(c)
+    subs = [sim.simulate_nonseparable(N, M, seed=s_id) for s_id in mine]       # subject s uses seed s (sim.py:361-363)
+    ctx = _lib.Context(local_rank)
+    ctx.set_data(subs[0]["x"], subs[0]["Y"])
+    ctx.svc_batch_alloc(len(mine))
+    ctx.svc_batch_set_subjects(np.stack([d["x"] for d in subs]), np.stack([d["Y"] for d in subs]))
+    ctx.svc_batch_set_pars(np.stack([sim.perturb(d["pars_true"], 0.05, 0.7) for d in subs]))
     want_grad = bool(a.grad)
 
     def step():
-        for c in ctxs:
-            c.svc_eval_resident(hv, True, want_grad)
-        return [c.svc_fetch(False)[0] for c in ctxs]
+        ctx.svc_batch_eval(hv, True, want_grad)
+        return ctx.svc_batch_fetch()
 
     for _ in range(a.warmup):
-        outs = step()
+        outs, status = step()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        for c in ctxs:
-            c.sync()
+        ctx.sync()
 
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        outs = step()
+        outs, status = step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, world, torch, dist)
-    rows = np.array([[s_id, 1.0, a.steps] + [float(v) for v in o[:5]] for s_id, o in zip(mine, outs)])
+    rows = np.array([[s_id, float(st == 0), a.steps] + [float(v) for v in o[:5]]
+                     for s_id, o, st in zip(mine, outs, status)])
     stats, table = chains.reduce_rows(rows, n_subj, world, device="cuda")
     if rank == 0:
         total = a.steps * n_subj
@@ -246,11 +245,11 @@ def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
             "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d independent subjects (%d per GPU, one stream each), nlogpos_obj_SVC %s, D=%d, "
-                                   "N=%d" % (n_subj, a.subjects_per_gpu, "value+gradient" if want_grad else "value", M, N),
+            "config": {"workload": "%d independent subjects (%d per GPU, one multi-subject batch per GPU), "
+                                   "nlogpos_obj_SVC %s, D=%d, N=%d" % (n_subj, a.subjects_per_gpu,
+                                                                       "value+gradient" if want_grad else "value", M, N),
                        "subjects_ok": int(stats[0]), "sum_neglog": float(stats[3])}}), flush=True)
-    for c in ctxs:
-        c.close()
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

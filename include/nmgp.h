@@ -93,6 +93,10 @@ int nmgp_svc_fetch(nmgp_ctx* ctx, double out5[5], double* grad);
  * positive definite; NMGP_NUM_NAN) -- a failing chain yields NaNs in its row, not a failed call. */
 int nmgp_svc_batch_alloc(nmgp_ctx* ctx, int B);
 int nmgp_svc_batch_set_pars(nmgp_ctx* ctx, const double* pars);
+/* Optional: make every batch element its own SUBJECT (x: [B,N], Y: [B,N,M] row-major; N, M as in nmgp_set_data) with
+ * its own GP-prior factors -- BASELINE config 4, the reference's one-process-per-subject pattern in one launch
+ * sequence.  Without this call all batch elements are chains of the subject given to nmgp_set_data. */
+int nmgp_svc_batch_set_subjects(nmgp_ctx* ctx, const double* x, const double* Y);
 double* nmgp_svc_batch_pars_dev(nmgp_ctx* ctx);
 int nmgp_svc_batch_eval(nmgp_ctx* ctx, const double hyper[8], int prior, int want_grad);
 int nmgp_svc_batch_fetch(nmgp_ctx* ctx, double* out, int* status);

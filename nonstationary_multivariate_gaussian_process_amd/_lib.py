@@ -41,6 +41,7 @@ SIGNATURES = {
     "nmgp_svc_fetch": (I, [V, P, P]),
     "nmgp_svc_batch_alloc": (I, [V, I]),
     "nmgp_svc_batch_set_pars": (I, [V, P]),
+    "nmgp_svc_batch_set_subjects": (I, [V, P, P]),
     "nmgp_svc_batch_pars_dev": (V, [V]),
     "nmgp_svc_batch_eval": (I, [V, P, I, I]),
     "nmgp_svc_batch_fetch_grad": (I, [V, P]),
@@ -216,6 +217,14 @@ class Context:
             raise NmgpError("batched parameters must be [B=%d, P=%d], got %s" % (self.B, P_, pars.shape))
         self.check(self.lib.nmgp_svc_batch_set_pars(self.h, ptr(pars)))
         self.sync()
+
+    def svc_batch_set_subjects(self, xs, Ys):
+        """Every batch element becomes its own subject: xs [B, N], Ys [B, N, M] (same N, M as set_data)."""
+        xs, Ys = as_f64(xs), as_f64(Ys)
+        if xs.shape != (self.B, self.N) or Ys.shape != (self.B, self.N, self.M):
+            raise NmgpError("subjects must be xs [B=%d, N=%d], Ys [B, N, M=%d]; got %s, %s"
+                            % (self.B, self.N, self.M, xs.shape, Ys.shape))
+        self.check(self.lib.nmgp_svc_batch_set_subjects(self.h, ptr(xs), ptr(Ys)))
 
     def svc_batch_eval(self, hyper, prior=True, want_grad=False):
         hyper = as_f64(hyper)

@@ -111,6 +111,15 @@ static void free_subject(nmgp_ctx* c) {
         double** bp[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                          &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr};
         c->b_grad_ready = false;
+        c->b_multi = false;
+        if (c->b_x) hipFree(c->b_x);
+        if (c->b_y) hipFree(c->b_y);
+        c->b_x = c->b_y = nullptr;
+        for (auto& pf : c->b_priors) {
+            if (pf.L) hipFree(pf.L);
+            if (pf.logdet) hipFree(pf.logdet);
+        }
+        c->b_priors.clear();
         for (double** p : bp) {
             if (*p) hipFree(*p);
             *p = nullptr;
@@ -527,6 +536,15 @@ static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr};
     c->b_grad_ready = false;
+    c->b_multi = false;
+    if (c->b_x) hipFree(c->b_x);
+    if (c->b_y) hipFree(c->b_y);
+    c->b_x = c->b_y = nullptr;
+    for (auto& pf : c->b_priors) {
+        if (pf.L) hipFree(pf.L);
+        if (pf.logdet) hipFree(pf.logdet);
+    }
+    c->b_priors.clear();
     for (double** p : ptrs) {
         if (*p) hipFree(*p);
         *p = nullptr;
@@ -571,6 +589,76 @@ extern "C" int nmgp_svc_batch_set_pars(nmgp_ctx* c, const double* pars) {
 
 extern "C" double* nmgp_svc_batch_pars_dev(nmgp_ctx* c) { return c ? c->b_pars : nullptr; }
 
+// Multi-subject batch (BASELINE config 4: many subjects of the same size, the reference runs one process per subject,
+// Nonseparable_model_mpisim.py:305-306): batch element b gets its own inputs x[b], Y[b] and its own GP-prior factors.
+// x: [B, N], Y: [B, N, M] row-major.  N and M are those of nmgp_set_data (whose subject is then ignored by the batch).
+extern "C" int nmgp_svc_batch_set_subjects(nmgp_ctx* c, const double* x, const double* Y) {
+    if (!c) return NMGP_E_NULL;
+    if (!x || !Y) return nmgp_fail(c, NMGP_E_NULL, "x/Y must not be NULL");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t B = c->batch, N = c->N, M = c->M, n = c->n;
+    hipStream_t s = c->stream;
+    if (!c->b_x) NMGP_TRY(nmgp_dev_alloc(c, &c->b_x, B * N));
+    if (!c->b_y) NMGP_TRY(nmgp_dev_alloc(c, &c->b_y, B * n));
+    double* tmp;
+    NMGP_TRY(nmgp_scratch_get(c, 2, B * n, &tmp));
+    HIP_TRY(c, hipMemcpyAsync(c->b_x, x, B * N * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(tmp, Y, B * n * sizeof(double), hipMemcpyHostToDevice, s));
+    for (size_t b = 0; b < B; ++b) transpose_y(s, tmp + b * n, (int)N, (int)M, c->b_y + b * n);
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (auto& pf : c->b_priors) {
+        if (pf.L) hipFree(pf.L);
+        if (pf.logdet) hipFree(pf.logdet);
+    }
+    c->b_priors.clear();
+    c->b_multi = true;
+    return 0;
+}
+
+// per-subject Cholesky factors of RBF(x_b; alpha, beta) + jitter I for the whole batch (one batched factorisation)
+static int get_batch_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
+    for (auto& p : c->b_priors)
+        if (p.alpha == alpha && p.beta == beta) {
+            *out = &p;
+            return 0;
+        }
+    PriorFactor pf;
+    pf.alpha = alpha;
+    pf.beta = beta;
+    const size_t N = c->N, B = c->batch;
+    pf.ld = (int)(((N + 15) / 16) * 16);
+    NMGP_TRY(nmgp_dev_alloc(c, &pf.L, B * (size_t)pf.ld * N));
+    if (nmgp_dev_alloc(c, &pf.logdet, B) != 0) {
+        hipFree(pf.L);
+        return NMGP_E_NOMEM;
+    }
+    int* info;
+    HIP_TRY(c, hipMalloc((void**)&info, B * sizeof(int)));
+    hipMemsetAsync(info, 0, B * sizeof(int), c->stream);
+    rbf_cov_sym(c->stream, c->b_x, c->N, alpha, beta, pf.L, pf.ld, false, (int)B);
+    potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, c->N), pf.L, pf.ld, c->N, 0, 0, c->chol_nb1, info, (int)B,
+                (long long)pf.ld * N, 1);
+    half_logdet(c->stream, pf.L, pf.ld, c->N, pf.logdet, (int)B);
+    std::vector<int> hi(B);
+    hipMemcpyAsync(hi.data(), info, B * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(info);
+    int bad = 0;
+    for (size_t b = 0; b < B; ++b)
+        if (hi[b] != 0 && bad == 0) bad = hi[b];
+    if (e != hipSuccess || bad != 0) {
+        hipFree(pf.L);
+        hipFree(pf.logdet);
+        if (e != hipSuccess) return nmgp_fail(c, NMGP_E_HIP, "batched prior factorisation failed (%s)", hipGetErrorString(e));
+        return nmgp_fail(c, bad, "GP prior covariance RBF(alpha=%g, beta=%g)+jitter of a subject is not positive definite "
+                         "(leading minor %d)", alpha, beta, bad);
+    }
+    c->b_priors.push_back(pf);
+    *out = &c->b_priors.back();
+    return 0;
+}
+
 static int batch_grad_alloc(nmgp_ctx* c) {
     if (c->b_grad_ready) return 0;
     const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc, B = c->batch;
@@ -603,20 +691,30 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
     const double a = hyper[6], b = hyper[7];
     hipStream_t s = c->stream;
+    const bool multi = c->b_multi;                  // every batch element is its own subject
+    const double* xs = multi ? c->b_x : c->d_x;
+    const int xstride = multi ? N : 0;
     PriorFactor *pl = nullptr, *pL = nullptr;
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
-    NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    if (multi) {
+        NMGP_TRY(get_batch_prior(c, al_l, be_l, &pl));
+        NMGP_TRY(get_batch_prior(c, al_L, be_L, &pL));
+        NMGP_TRY(get_batch_prior(c, al_l, be_l, &pl));
+    } else {
+        NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+        NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
+        NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    }
     HIP_TRY(c, hipMemsetAsync(c->b_info, 0, (size_t)B * sizeof(int), s));
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
-        int r = svc_cov_build(s, c->d_x, c->b_ell, c->b_Lv, c->b_pars + (P - 1), S, ld, N, M, false, B, bs);
+        int r = svc_cov_build(s, xs, c->b_ell, c->b_Lv, c->b_pars + (P - 1), S, ld, N, M, false, B, bs, xstride);
         if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     }
     {
         StageScope sp(c, NMGP_STAGE_CHOL);
-        set_row(s, S, ld, n, c->d_y, n, B, bs, 0);           // every chain shares y
+        // one subject: every chain shares y (vstride 0); multi-subject: y of batch element b
+        set_row(s, S, ld, n, multi ? c->b_y : c->d_y, n, B, bs, multi ? n : 0);
         if (want_grad) identity_rows(s, S, ld, n + 1, n, xpad, B, bs);
         potrf_lower(s, c->stream2, nmgp_chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
                     c->b_info, B, bs, 1);
@@ -645,7 +743,23 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
             if (pass == 1)
                 HIP_TRY(c, hipMemcpyAsync(c->b_R2, c->b_R, (size_t)N * B * (1 + T) * sizeof(double),
                                           hipMemcpyDeviceToDevice, s));
-            if (same) {
+            if (multi) {
+                // per-subject factors: strided-batched solves (columns of chain b start at b (1+T) N)
+                const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;
+                const rocblas_stride sB = (rocblas_stride)(1 + T) * N;
+                if (same) {
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                                                              rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, sA_l,
+                                                              R, N, sB, B));
+                } else {
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                                                              rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, sA_l, R,
+                                                              N, sB, B));
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                                                              rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, sA_L,
+                                                              R + N, N, sB, B));
+                }
+            } else if (same) {
                 // one multi-right-hand-side solve for the whole batch: the prior factor depends on (x, alpha, beta) only
                 BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
                                           B * (1 + T), &one, pl->L, pl->ld, R, N));
@@ -665,7 +779,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         StageScope sp(c, NMGP_STAGE_REDUCE);
         const double ig_const = a * std::log(b) - std::lgamma(a);
         svc_finalize(s, c->b_scal, c->b_scal + 1, c->b_q, pl->logdet, pL->logdet, c->b_pars, P, N, T, a, b, ig_const,
-                     prior, c->b_scal + 8, B, 16);
+                     prior, c->b_scal + 8, B, 16, multi ? 1 : 0);
     }
     if (want_grad) {
         {
@@ -677,7 +791,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         {
             StageScope sp(c, NMGP_STAGE_ADJOINT);
             trace_terms(s, c->b_alpha, c->b_Sinv, n, n, c->b_tr, -1.0, B);
-            int r = svc_adjoint(s, c->d_x, c->b_ell, c->b_Lv, c->b_alpha, c->b_Sinv, n, N, M, c->b_part, -1.0, B);
+            int r = svc_adjoint(s, xs, c->b_ell, c->b_Lv, c->b_alpha, c->b_Sinv, n, N, M, c->b_part, -1.0, B, xstride);
             if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
             svc_grad_final(s, c->b_part, (N + 63) / 64, N, M, c->b_Lv, c->b_R2, N, c->b_pars, c->b_tr, a, b, prior,
                            c->b_grad, B);

@@ -42,17 +42,17 @@ __device__ __forceinline__ int clamp_row_pair(int r, int rows) {
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
 // NWJ = column groups of waves per 128x128 tile: 2 -> 4 waves of 64x64 (16 MFMA tiles each), 4 -> 8 waves of 64x32
 // (8 MFMA tiles each, ~110 VGPRs, so four waves per SIMD hide each other's barrier / LDS / prologue stalls).
-template <int NWJ>
-__global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __restrict__ A, int lda,
+template <int NWJ, int BK>
+__global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_lower(const double* __restrict__ A, int lda,
                                                                  double* __restrict__ C, int ldc, int mrows, int ncols,
                                                                  int K, long long bstride, long long cstride, int ktri) {
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
-    constexpr int NQ = 1024 / NT;          // 16-byte loads per thread per operand and k-step
+    constexpr int NQ = (64 * BK) / NT;     // 16-byte loads per thread per operand and k-step
     constexpr int CGS = NT / 64;           // k-columns covered per load round
-    __shared__ double sA[2][SY_BK * SY_LD];
-    __shared__ double sB[2][SY_BK * SY_LD];
+    __shared__ double sA[2][BK * SY_LD];
+    __shared__ double sB[2][BK * SY_LD];
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (bi < bj) return;
     A += (size_t)blockIdx.z * bstride;       // batch of independent matrices (one per chain), same shape
@@ -98,11 +98,11 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
 
     // a wave whose sub-tile lies strictly above the diagonal has nothing to compute
     const bool active = !(diag && (wi * 64 + 63 < wj * CW));
-    const int nk = (K + SY_BK - 1) / SY_BK;
+    const int nk = (K + BK - 1) / BK;
     // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
     // first row contribute nothing
-    const int kt0 = ktri ? (row0 / SY_BK) : 0;
-    gload(kt0 * SY_BK);
+    const int kt0 = ktri ? (row0 / BK) : 0;
+    gload(kt0 * BK);
     // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
     // the MFMA negated, so the k-loop leaves C - A A^T in registers and the epilogue is stores only.
     // D[row = (lane>>4) + 4 reg <-> j][col = lane&15 <-> i]
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
                 const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
                 acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
-    sstore(0, kt0 * SY_BK);
+    sstore(0, kt0 * BK);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
         const int cur = (kt - kt0) & 1;
-        if (kt + 1 < nk) gload((kt + 1) * SY_BK);
+        if (kt + 1 < nk) gload((kt + 1) * BK);
         if (active) {
             const double* tA = sA[cur] + wi * 64 + (lane & 15) + (lane >> 4) * SY_LD;
             const double* tB = (diag ? sA[cur] : sB[cur]) + wj * CW + (lane & 15) + (lane >> 4) * SY_LD;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
 #pragma unroll
             for (int t = 0; t < TJ; ++t) fb[t] = -tB[t * 16];
 #pragma unroll
-            for (int kk = 0; kk < SY_BK / 4; ++kk) {
-                if (kk + 1 < SY_BK / 4) {
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                if (kk + 1 < BK / 4) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) na[t] = tA[(kk + 1) * 4 * SY_LD + t * 16];
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti)
                         acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tj], fa[ti], acc[tj][ti], 0, 0, 0);
-                if (kk + 1 < SY_BK / 4) {
+                if (kk + 1 < BK / 4) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) fa[t] = na[t];
 #pragma unroll
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
                 }
             }
         }
-        if (kt + 1 < nk) sstore(cur ^ 1, (kt + 1) * SY_BK);
+        if (kt + 1 < nk) sstore(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
     }
     if (!active) return;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(128 * NWJ, NWJ) void k_syrk_lower(const double* __r
 }
 
 static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
+static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride, int ktri) {
@@ -177,13 +178,17 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
     if (g_syrk_nwj == 0) {
         const char* e = std::getenv("NMGP_SYRK_WAVES");
         g_syrk_nwj = (e && std::atoi(e) == 4) ? 2 : 4;
+        const char* b = std::getenv("NMGP_SYRK_BK");
+        g_syrk_bk = (b && std::atoi(b) == 32) ? 32 : 16;
     }
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
     const long long cs = cstride < 0 ? bstride : cstride;
     if (g_syrk_nwj == 2)
-        hipLaunchKernelGGL((k_syrk_lower<2>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+    else if (g_syrk_bk == 32)
+        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
     else
-        hipLaunchKernelGGL((k_syrk_lower<4>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -106,6 +106,11 @@ struct nmgp_ctx {
     double* b_R2 = nullptr;     // [N, B (1+T)]
     double* b_tr = nullptr;     // [B, 2]
     bool b_last_grad = false;
+    // multi-subject batch: every batch element has its own (x, Y) and its own prior factors
+    bool b_multi = false;
+    double* b_x = nullptr;      // [B, N]
+    double* b_y = nullptr;      // [B, n] output-major
+    std::vector<PriorFactor> b_priors;   // L: [B] x (ld x N), logdet: [B]
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
 
@@ -160,9 +165,10 @@ namespace nmgpk {
 void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv, int batch = 1);
 // kernel #1: fused nonseparable covariance (lower triangle, column-major, output-major indices)
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                  double* S, int ld, int N, int M, bool full, int batch = 1, long long sstride = 0);
+                  double* S, int ld, int N, int M, bool full, int batch = 1, long long sstride = 0, int xstride = 0);
 // symmetric N x N builds (lower triangle unless full)
-void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full);
+void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full,
+                 int batch = 1);
 void gibbs_cov_sym(hipStream_t s, const double* x, const double* sig, const double* ell, int N, double* out, int ld,
                    bool full);
 // rectangular d-dimensional primitives, row-major output [n1, n2]
@@ -183,7 +189,8 @@ void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l,
                    int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1);
+                const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
+                int xstride = 0);
 void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out,
                  double ssign = 1.0, int batch = 1);
 void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,
@@ -191,8 +198,8 @@ void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, con
                     int batch = 1);
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5, int batch = 1, int sstride = 0);
-void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out);
+                  double ig_const, int prior, double* out5, int batch = 1, int sstride = 0, int hstride = 0);
+void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int batch = 1);
 // ---- nmgp_kernels_eig.hip ----
 int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, const double* B, int m1, int m2,
             double* out);

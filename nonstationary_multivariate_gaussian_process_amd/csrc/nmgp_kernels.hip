@@ -69,13 +69,16 @@ void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, doub
 template <int M, bool FULL>
 __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, const double* __restrict__ ell,
                                                   const double* __restrict__ Lv, const double* __restrict__ tse,
-                                                  double* __restrict__ S, int ld, int N, long long sstride) {
+                                                  double* __restrict__ S, int ld, int N, long long sstride,
+                                                  int xstride) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T];
     const int I = blockIdx.x, J = blockIdx.y;
     if (!FULL && M == 1 && I < J) return;
-    // blockIdx.z = chain of the batch (same x for all chains, one covariance buffer per chain)
+    // blockIdx.z = chain of the batch: one covariance buffer per chain; xstride = 0 when all chains belong to one
+    // subject (shared x), N when every batch element is its own subject
+    x += (size_t)blockIdx.z * xstride;
     ell += (size_t)blockIdx.z * N;
     Lv += (size_t)blockIdx.z * N * T;
     tse += (size_t)blockIdx.z * ((size_t)N * (1 + T) + 1);
@@ -133,25 +136,25 @@ __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, c
 
 template <int M>
 static void launch_svc_cov(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                           double* S, int ld, int N, bool full, int batch, long long sstride) {
+                           double* S, int ld, int N, bool full, int batch, long long sstride, int xstride) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
-        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride);
+        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
     else
-        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride);
+        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
 }
 
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse, double* S,
-                  int ld, int N, int M, bool full, int batch, long long sstride) {
+                  int ld, int N, int M, bool full, int batch, long long sstride, int xstride) {
     switch (M) {
-        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
-        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride); break;
+        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
         default: return NMGP_E_UNSUPPORTED;
     }
     return 0;
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(256) void k_cov_sym(const double* __restrict__ x, c
     __shared__ double sx[TJ], sl[TJ], ss[TJ];
     const int I = blockIdx.x, J = blockIdx.y;
     if (!FULL && I < J) return;
+    x += (size_t)blockIdx.z * N;                      // blockIdx.z = subject of a multi-subject batch
+    out += (size_t)blockIdx.z * ld * N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j0 = J * TJ;
     if (tid < TJ) {
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(256) void k_cov_sym(const double* __restrict__ x, c
     }
 }
 
-void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full) {
-    dim3 grid(cdiv(N, 64), cdiv(N, 64));
+void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full,
+                 int batch) {
+    dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
         hipLaunchKernelGGL((k_cov_sym<false, true>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
     else
@@ -432,10 +438,11 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
                                                       const double* __restrict__ Lv,
                                                       const double* __restrict__ alpha,
                                                       const double* __restrict__ Sinv, int ld, int N,
-                                                      double* __restrict__ part, double ssign) {
+                                                      double* __restrict__ part, double ssign, int xstride) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T], sa[TJ * M];
+    x += (size_t)blockIdx.z * xstride;
     __shared__ double red[2][4][64];
     const int I = blockIdx.x, J = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -522,10 +529,10 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
 
 // ssign = +1 when Sinv holds Sigma^-1 (rocSOLVER potri), -1 when it holds -Sigma^-1 (C -= X X^T of the custom path)
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch) {
+                const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch, int xstride) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);      // batched: Sinv matrices are ld x (N M) apart (ld == N M there)
 #define NMGP_ADJ(MM) \
-    hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign)
+    hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign, xstride)
     switch (M) {
         case 1: NMGP_ADJ(1); break;
         case 2: NMGP_ADJ(2); break;
@@ -629,8 +636,10 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
                                const double* __restrict__ q, const double* __restrict__ hl_l,
                                const double* __restrict__ hl_L, const double* __restrict__ pars, long long P, int N,
                                int T, double a, double b, double ig_const, int prior, double* __restrict__ out5,
-                               int sstride) {
+                               int sstride, int hstride) {
     if (threadIdx.x != 0) return;
+    hl_l += (size_t)blockIdx.x * hstride;      // per-subject prior factors in a multi-subject batch
+    hl_L += (size_t)blockIdx.x * hstride;
     // blockIdx.x = chain: scalar blocks are sstride apart, prior terms 1 + T apart, parameter vectors P apart
     logdet += (size_t)blockIdx.x * sstride;
     quad += (size_t)blockIdx.x * sstride;
@@ -662,23 +671,25 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
 
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5, int batch, int sstride) {
+                  double ig_const, int prior, double* out5, int batch, int sstride, int hstride) {
     hipLaunchKernelGGL(k_svc_finalize, dim3(batch), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
-                       ig_const, prior, out5, sstride);
+                       ig_const, prior, out5, sstride, hstride);
 }
 
 // half log-determinant of a Cholesky factor: sum log L_rr
 __global__ __launch_bounds__(1024) void k_half_logdet(const double* __restrict__ L, int ld, int n,
                                                        double* __restrict__ out) {
     __shared__ double sh[16];
+    L += (size_t)blockIdx.x * ld * n;
+    out += blockIdx.x;
     double a = 0.0;
     for (int r = threadIdx.x; r < n; r += blockDim.x) a += log(L[(size_t)r * ld + r]);
     a = block_sum(a, sh);
     if (threadIdx.x == 0) out[0] = a;
 }
 
-void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out) {
-    hipLaunchKernelGGL(k_half_logdet, dim3(1), dim3(1024), 0, s, L, ld, n, out);
+void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int batch) {
+    hipLaunchKernelGGL(k_half_logdet, dim3(batch), dim3(1024), 0, s, L, ld, n, out);
 }
 
 }  // namespace nmgpk

@@ -421,3 +421,26 @@ def test_separable_cholesky_and_eigen_formulations_agree():
         a, b = res[("chol", name)], res[("eig", name)]
         assert relerr(a[0][1], b[0][1]) < 1e-9 and relerr(a[0], b[0]) < 1e-9
         assert vec_relerr(a[1], b[1]) < 1e-7
+
+
+def test_multi_subject_batch_matches_per_subject_evaluations(ctx):
+    """BASELINE config 4 pattern: several subjects (own x, Y, own prior factors) in ONE launch sequence."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    N, M, B = 96, 3, 5
+    subs = [sim.simulate_nonseparable(N, M, seed=s) for s in range(B)]
+    hyper = sim.HYPER_SVC_MPISIM
+    hv = [hyper[k] for k in SVC_KEYS]
+    pars = np.stack([sim.perturb(d["pars_true"], 0.03, 0.2 * k) for k, d in enumerate(subs)])
+    ctx.set_data(subs[0]["x"], subs[0]["Y"])
+    ctx.svc_batch_alloc(B)
+    ctx.svc_batch_set_subjects(np.stack([d["x"] for d in subs]), np.stack([d["Y"] for d in subs]))
+    ctx.svc_batch_set_pars(pars)
+    ctx.svc_batch_eval(hv, True, want_grad=True)
+    out, status = ctx.svc_batch_fetch()
+    grads = ctx.svc_batch_fetch_grad()
+    assert np.all(status == 0)
+    for k, d in enumerate(subs):
+        ctx.set_data(d["x"], d["Y"])
+        single, gsingle = ctx.logpos_svc(pars[k], hv, prior=True, want_grad=True)
+        assert relerr(out[k][1], single[1]) < 1e-11 and relerr(out[k], single) < 1e-8, (k, out[k], single)
+        assert vec_relerr(grads[k], gsingle) < 1e-8
