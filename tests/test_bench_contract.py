@@ -1,0 +1,51 @@
+"""bench.py contract: one JSON line with the required keys, `roofline` and `cpu_baseline` objects (GPU), and the CPU
+baseline helper on its own (CPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def test_cpu_baseline_helper_runs_on_cpu():
+    sys.path.insert(0, ROOT)
+    import bench
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    d = sim.simulate_nonseparable(48, 2, seed=1)
+    rec = bench.cpu_baseline(d, d["pars_true"], sim.HYPER_SVC, 1, False)
+    assert rec["kind"] == "port" and rec["unit"] == "evals/s" and rec["value"] > 0 and rec["cores"] >= 1
+    assert "sample" in rec and "N=48" in rec["sample"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--chains", "3"], ["--chains", "1", "--grad"],
+                                   ["--workload", "subjects", "--subjects-per-gpu", "3"]])
+def test_bench_prints_one_valid_json_line(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--N", "96", "--M", "3", "--steps", "2", "--warmup", "1",
+           "--cpu-evals", "1"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    if "subjects" in extra:
+        assert rec["value"] > 0 and rec["config"]["subjects_ok"] == 3 and rec["scaling"] == "weak"
+        return
+    for k in REQUIRED:
+        assert k in rec, k
+    assert rec["unit"] == "evals/s" and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["dtype"] == "f64"
+    assert rec["higher_is_better"] is True and rec["vs_baseline"] is None and rec["data"] == "synthetic"
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    rl = rec["roofline"]
+    assert rl["bound"] in ("hbm", "mfma") and rl["unit"] == "TFLOP/s" and rl["peak"] > 0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12 and "traffic" in rl
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert np.isfinite(rec["value"]) and rec["value"] > 0
