@@ -38,7 +38,8 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (vendor dense figure; SU
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per batched factorisation from the rocprofv3 PMC passes (profiles/, filled in by hand from the committed
 # counter CSVs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 32): 1.755e11}    # (N, M, chains) -> bytes; profiles/r01_v3_batched32_pmc_traffic.json
+TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 32): 1.600e11}    # (N, M, chains) -> HBM bytes of the k_syrk_lower launches of one
+#                                                         batched factorisation; profiles/r01_v4_batched32_pmc_traffic.json
 
 
 def main():
@@ -138,6 +139,15 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
+    # dominant-kernel pass: the same K steps again with one HIP-event pair around EVERY k_syrk_lower launch (on the
+    # stream it is launched on); kept out of the timed region so the ~200 extra event records per factorisation do not
+    # leak into `value`
+    ctx.profile_enable(2)
+    ctx.profile_reset()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    kprof = ctx.profile_read_work()
     ctx.profile_enable(False)
 
     elapsed_max = max_over_ranks(elapsed, world, torch, dist)
@@ -150,11 +160,19 @@ def main():
     if rank == 0:
         chol_ms, chol_cnt = prof["chol"]
         chol_avg_s = (chol_ms / max(chol_cnt, 1)) * 1e-3
-        flops = B * n ** 3 / 3.0
-        achieved = flops / chol_avg_s / 1e12 if chol_avg_s > 0 else 0.0
+        B0 = (B // G + (1 if B % G else 0)) if B > 1 else 1     # chains in the profiled context (group 0)
+        flops = B0 * n ** 3 / 3.0
+        chol_tf = flops / chol_avg_s / 1e12 if chol_avg_s > 0 else 0.0
+        # k_syrk_lower: sum of algorithmic flop (2K per updated lower-trapezoid element) / sum of launch durations
+        syrk_ms, syrk_cnt, syrk_flop, syrk_bytes = kprof["syrk"]
+        achieved = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        syrk_info = {"launches_per_step": syrk_cnt / max(a.steps, 1), "avg_launch_us": 1e3 * syrk_ms / max(syrk_cnt, 1),
+                     "ms_per_step": syrk_ms / max(a.steps, 1), "gflop_per_step": syrk_flop / max(a.steps, 1) / 1e9,
+                     "algorithmic_bytes_per_step": syrk_bytes / max(a.steps, 1),
+                     "share_of_factorisation_flop": syrk_flop / max(a.steps, 1) / flops}
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1] > 0}
         cov_ms = stage_ms.get("cov", 0.0)
-        cov_bytes = B * 8.0 * n * (n + 1) / 2.0
+        cov_bytes = B0 * 8.0 * n * (n + 1) / 2.0
         try:
             dgemm_tf = ctx.measure_dgemm_tflops(4096, 5)
             hbm_gbs = ctx.measure_hbm_gbs(1 << 30, 10)
@@ -173,12 +191,19 @@ def main():
                        "chains_ok": int(chain_stats[0]), "sum_neglog_all_chains": float(chain_stats[3]),
                        "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,
                        "cov_build_gbs": (cov_bytes / (cov_ms * 1e-3) / 1e9) if cov_ms > 0 else None},
-            "roofline": {"kernel": "blocked FP64 Cholesky of %d %dx%d covariances per launch sequence: k_syrk_lower "
-                                   "(v_mfma_f64_16x16x4_f64 trailing updates) + k_potf2_64 / k_trsm_64 panel steps; "
-                                   "algorithmic flop = chains * n^3/3, time = HIP events around the stage" % (B, n, n),
+            "roofline": {"kernel": "k_syrk_lower (v_mfma_f64_16x16x4_f64 trailing update of the blocked FP64 Cholesky of "
+                                   "%d %dx%d covariances): achieved = sum over launches of 2K*(updated lower-trapezoid "
+                                   "elements) / sum of HIP-event launch durations on the launching stream" % (B, n, n),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((N, M, B))},
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((N, M, B)),
+                         "traffic_note": "HBM bytes of the k_syrk_lower launches of ONE step (same scope as syrk.gflop_per_step), from "
+                                         "the rocprofv3 FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes committed under profiles/",
+                         "syrk": syrk_info,
+                         "factorisation": {"what": "whole CHOL stage (syrk + potf2 + trsm + row moves), chains*n^3/3 flop "
+                                                   "over the HIP-event stage time of the timed region",
+                                           "ms": 1e3 * chol_avg_s, "achieved": chol_tf,
+                                           "frac": chol_tf / FP64_MATRIX_PEAK_TFLOPS}},
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(d, pars, hyper, a.cpu_evals, want_grad)

@@ -185,12 +185,18 @@ enum {
     NMGP_STAGE_ADJOINT = 6, /* fused adjoint contraction (kernel #5)         */
     NMGP_STAGE_EIG = 7,     /* eigendecomposition (separable / stationary)   */
     NMGP_STAGE_KRONMV = 8,  /* Kron-vec contraction (kernel #3)              */
-    NMGP_STAGE_COUNT = 9
+    NMGP_STAGE_SYRK = 9,    /* every k_syrk_lower launch of the blocked Cholesky (FP64 MFMA), timed on its own stream */
+    NMGP_STAGE_COUNT = 10
 };
-int nmgp_profile_enable(nmgp_ctx* ctx, int on);
+int nmgp_profile_enable(nmgp_ctx* ctx, int on);   /* 0 off; 1 one HIP-event pair per stage; 2 additionally one pair per k_syrk_lower launch */
 /* Accumulated milliseconds and launch counts per stage since the last reset; synchronises. */
 int nmgp_profile_read(nmgp_ctx* ctx, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT]);
 int nmgp_profile_reset(nmgp_ctx* ctx);
+/* As nmgp_profile_read, plus the algorithmic work accumulated per stage; tracked for NMGP_STAGE_SYRK only (0 elsewhere):
+ * flop = 2 K per updated lower-trapezoid element of every launch, bytes = 8 * (read + write of those elements + the
+ * mrows x K panel read once). */
+int nmgp_profile_read_work(nmgp_ctx* ctx, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT],
+                           double flop[NMGP_STAGE_COUNT], double bytes[NMGP_STAGE_COUNT]);
 /* Micro-benchmarks used to state measured peaks next to the spec ones: HBM stream (GB/s) and a
  * rocBLAS dgemm of size n (TFLOP/s). */
 int nmgp_measure_hbm_gbs(nmgp_ctx* ctx, long long bytes, int reps, double* gbs);

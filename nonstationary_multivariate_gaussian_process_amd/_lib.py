@@ -22,7 +22,7 @@ I, D, P, V = ctypes.c_int, ctypes.c_double, c_double_p, ctypes.c_void_p
 
 NUM_NAN = 1 << 20
 NUM_EIG = (1 << 20) + 1
-STAGES = ["cov", "chol", "solve", "reduce", "prior", "inverse", "adjoint", "eig", "kronmv"]
+STAGES = ["cov", "chol", "solve", "reduce", "prior", "inverse", "adjoint", "eig", "kronmv", "syrk"]
 
 # name -> (restype, argtypes); must list every function declared in include/nmgp.h
 SIGNATURES = {
@@ -66,6 +66,7 @@ SIGNATURES = {
     "nmgp_profile_enable": (I, [V, I]),
     "nmgp_profile_read": (I, [V, P, c_ll_p]),
     "nmgp_profile_reset": (I, [V]),
+    "nmgp_profile_read_work": (I, [V, P, c_ll_p, P, P]),
     "nmgp_measure_hbm_gbs": (I, [V, ctypes.c_longlong, I, P]),
     "nmgp_measure_dgemm_tflops": (I, [V, I, I, P]),
 }
@@ -379,7 +380,7 @@ class Context:
 
     # -- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self.check(self.lib.nmgp_profile_enable(self.h, int(bool(on))))
+        self.check(self.lib.nmgp_profile_enable(self.h, int(on)))   # True/1 stage timers, 2 + per-launch SYRK timers
 
     def profile_reset(self):
         self.check(self.lib.nmgp_profile_reset(self.h))
@@ -389,6 +390,15 @@ class Context:
         cnt = np.zeros(len(STAGES), dtype=np.int64)
         self.check(self.lib.nmgp_profile_read(self.h, ptr(ms), cnt.ctypes.data_as(c_ll_p)))
         return {s: (float(ms[k]), int(cnt[k])) for k, s in enumerate(STAGES)}
+
+    def profile_read_work(self):
+        """{stage: (ms, launches, algorithmic flop, algorithmic bytes)}; tracked for "syrk", 0 elsewhere."""
+        ms = np.zeros(len(STAGES))
+        cnt = np.zeros(len(STAGES), dtype=np.int64)
+        work = np.zeros(len(STAGES))
+        nbytes = np.zeros(len(STAGES))
+        self.check(self.lib.nmgp_profile_read_work(self.h, ptr(ms), cnt.ctypes.data_as(c_ll_p), ptr(work), ptr(nbytes)))
+        return {s: (float(ms[k]), int(cnt[k]), float(work[k]), float(nbytes[k])) for k, s in enumerate(STAGES)}
 
     def measure_hbm_gbs(self, nbytes=1 << 30, reps=10):
         out = np.empty(1)

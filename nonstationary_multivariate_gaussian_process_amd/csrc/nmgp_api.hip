@@ -29,7 +29,22 @@ int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...) {
 
 // ---- profiling helpers ---------------------------------------------------------------------------
 typedef NmgpStage StageScope;
-NmgpStage::NmgpStage(nmgp_ctx* ctx, int st) : c(ctx), stage(st) {
+NmgpStage::NmgpStage(nmgp_ctx* ctx, int st, hipStream_t s, double work, double bytes) : c(ctx), stage(st), stream(s) {
+        if (!c->profiling) return;
+        StageTimer& t = c->timers[stage];
+        t.work += work;
+        t.bytes += bytes;
+        if (!t.pool.empty()) {
+            e0 = t.pool.back().first;
+            e1 = t.pool.back().second;
+            t.pool.pop_back();
+        } else {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+        }
+        hipEventRecord(e0, stream);
+}
+NmgpStage::NmgpStage(nmgp_ctx* ctx, int st) : c(ctx), stage(st), stream(ctx->stream) {
         if (!c->profiling) return;
         StageTimer& t = c->timers[stage];
         if (!t.pool.empty()) {
@@ -40,12 +55,26 @@ NmgpStage::NmgpStage(nmgp_ctx* ctx, int st) : c(ctx), stage(st) {
             hipEventCreate(&e0);
             hipEventCreate(&e1);
         }
-        hipEventRecord(e0, c->stream);
+        hipEventRecord(e0, stream);
 }
 NmgpStage::~NmgpStage() {
         if (!c->profiling || !e0) return;
-        hipEventRecord(e1, c->stream);
+        hipEventRecord(e1, stream);
         c->timers[stage].pending.push_back({e0, e1});
+}
+
+static void* syrk_hook_begin(void* user, hipStream_t s, double flop, double bytes) {
+    nmgp_ctx* c = static_cast<nmgp_ctx*>(user);
+    if (c->profiling < 2) return nullptr;
+    return new NmgpStage(c, NMGP_STAGE_SYRK, s, flop, bytes);
+}
+static void syrk_hook_end(void*, void* token) { delete static_cast<NmgpStage*>(token); }
+
+const SyrkHook* nmgp_syrk_hook(nmgp_ctx* c) {
+    c->syrk_hook.user = c;
+    c->syrk_hook.begin = syrk_hook_begin;
+    c->syrk_hook.end = syrk_hook_end;
+    return &c->syrk_hook;
 }
 
 static void profile_collect(nmgp_ctx* c) {
@@ -328,7 +357,7 @@ hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n) {
 
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
     if (c->chol_algo == 1 && (ld % 2 == 0)) {
-        potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0);
+        potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0, nmgp_syrk_hook(c));
         return 0;
     }
     if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
@@ -380,7 +409,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
             if (want_grad) identity_rows(s, c->d_S, ld, n + 1, n, xpad);
             // row n becomes z = L^-1 y
             potrf_lower(s, c->stream2, nmgp_chol_events(c, n), c->d_S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0,
-                        c->chol_nb1, c->d_info, 1, 0, 0);
+                        c->chol_nb1, c->d_info, 1, 0, 0, nmgp_syrk_hook(c));
         }
         {
             StageScope sp(c, NMGP_STAGE_SOLVE);
@@ -638,7 +667,7 @@ static int get_batch_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor**
     hipMemsetAsync(info, 0, B * sizeof(int), c->stream);
     rbf_cov_sym(c->stream, c->b_x, c->N, alpha, beta, pf.L, pf.ld, false, (int)B);
     potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, c->N), pf.L, pf.ld, c->N, 0, 0, c->chol_nb1, info, (int)B,
-                (long long)pf.ld * N, 1);
+                (long long)pf.ld * N, 1, nmgp_syrk_hook(c));
     half_logdet(c->stream, pf.L, pf.ld, c->N, pf.logdet, (int)B);
     std::vector<int> hi(B);
     hipMemcpyAsync(hi.data(), info, B * sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -717,7 +746,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         set_row(s, S, ld, n, multi ? c->b_y : c->d_y, n, B, bs, multi ? n : 0);
         if (want_grad) identity_rows(s, S, ld, n + 1, n, xpad, B, bs);
         potrf_lower(s, c->stream2, nmgp_chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
-                    c->b_info, B, bs, 1);
+                    c->b_info, B, bs, 1, nmgp_syrk_hook(c));
     }
     {
         StageScope sp(c, NMGP_STAGE_SOLVE);
@@ -879,7 +908,7 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     if (algo == 1) {
         StageScope sp(c, NMGP_STAGE_CHOL);
         if (rhs) set_row(s, dA, (int)ld, n, dv, n, 1, 0, 0);
-        potrf_lower(s, c->stream2, nmgp_chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, 0, c->chol_nb1, c->d_info + 5, 1, 0, 0);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, n), dA, (int)ld, n, rhs ? 1 : 0, 0, c->chol_nb1, c->d_info + 5, 1, 0, 0, nmgp_syrk_hook(c));
         if (rhs) get_row(s, dA, (int)ld, n, dv + n, n, 1, 0, 0);
     } else {
         StageScope sp(c, NMGP_STAGE_CHOL);
@@ -1005,7 +1034,7 @@ extern "C" int nmgp_kron_product(nmgp_ctx* c, const double* a, int ar, int ac, c
 // ---- profiling / micro-benchmarks ----------------------------------------------------------------
 extern "C" int nmgp_profile_enable(nmgp_ctx* c, int on) {
     if (!c) return NMGP_E_NULL;
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : on;
     return 0;
 }
 
@@ -1017,7 +1046,21 @@ extern "C" int nmgp_profile_reset(nmgp_ctx* c) {
     for (auto& t : c->timers) {
         t.ms = 0;
         t.count = 0;
+        t.work = 0;
+        t.bytes = 0;
     }
+    return 0;
+}
+
+extern "C" int nmgp_profile_read_work(nmgp_ctx* c, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT],
+                                      double work[NMGP_STAGE_COUNT], double bytes[NMGP_STAGE_COUNT]) {
+    if (!c) return NMGP_E_NULL;
+    int r = nmgp_profile_read(c, ms, count);
+    if (r) return r;
+    if (work)
+        for (int s = 0; s < NMGP_STAGE_COUNT; ++s) work[s] = c->timers[s].work;
+    if (bytes)
+        for (int s = 0; s < NMGP_STAGE_COUNT; ++s) bytes[s] = c->timers[s].bytes;
     return 0;
 }
 

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
             }
 }
 
+static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
 static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
 static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
@@ -183,13 +184,21 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
     }
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
     const long long cs = cstride < 0 ? bstride : cstride;
+    void* tok = nullptr;
+    if (g_hook && g_hook->begin) {
+        // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
+        const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
+        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
+    }
     if (g_syrk_nwj == 2)
         hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
     else if (g_syrk_bk == 32)
         hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
     else
         hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+    if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
@@ -478,8 +487,15 @@ static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, in
 // (or ev == nullptr) selects the plain single-stream order.
 // batch > 1 factors `batch` matrices of identical shape at once (matrix b at A + b * bstride, status word at
 // info + b * istride): every launch covers all of them, so the latency of the 64-wide steps is paid once per batch.
+struct HookScope {
+    const SyrkHook* prev;
+    explicit HookScope(const SyrkHook* h) : prev(g_hook) { g_hook = h; }
+    ~HookScope() { g_hook = prev; }
+};
+
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
-                 int nb1, int* info, int batch, long long bstride, int istride) {
+                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook) {
+    HookScope hs(hook);
     const int is = istride;
     const long long bs = bstride;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);

@@ -290,7 +290,7 @@ int kron_chol_loglik(nmgp_ctx* c, EigWork& w, double sigma2, bool want_grad, dou
         set_row(s, S, ld, N, yt, N, M, bs, N);
         if (want_grad) identity_rows(s, S, ld, N + 1, N, xpad, M, bs);
         potrf_lower(s, c->stream2, nmgp_chol_events(c, N), S, ld, N, want_grad ? 1 + xpad : 1, want_grad ? N : 0,
-                    c->chol_nb1, info, M, bs, 1);
+                    c->chol_nb1, info, M, bs, 1, nmgp_syrk_hook(c));
         get_row(s, S, ld, N, z, N, M, bs, N);
     }
     {

@@ -38,6 +38,15 @@ struct StageTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double ms = 0;
     long long count = 0;
+    double work = 0;   // algorithmic flop of the timed launches, where tracked
+    double bytes = 0;  // algorithmic HBM bytes of the timed launches, where tracked
+};
+
+// optional per-launch profiling of k_syrk_lower: begin() before / end() after each launch, on the launch's stream
+struct SyrkHook {
+    void* user = nullptr;
+    void* (*begin)(void* user, hipStream_t s, double flop, double bytes) = nullptr;
+    void (*end)(void* user, void* token) = nullptr;
 };
 
 struct nmgp_ctx {
@@ -45,7 +54,8 @@ struct nmgp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation
     std::vector<hipEvent_t> chol_ev;          // events ordering the two streams
-    int chol_lookahead = 1;
+    int chol_lookahead = 0;                   // far trailing update on stream2 (+-2 %; off keeps kernel timings exclusive)
+    SyrkHook syrk_hook;
     int sep_algo = 1;                         // separable/stationary likelihood: 1 = M batched Cholesky blocks, 0 = dsyevd
     rocblas_handle blas = nullptr;
     std::string err;
@@ -116,7 +126,7 @@ struct nmgp_ctx {
 
     int chol_algo = 1;          // 0 = rocSOLVER dpotrf + rocBLAS dtrsv, 1 = custom blocked factorisation (nmgp_chol.hip)
     int chol_nb1 = 512;         // outer panel width of the custom factorisation
-    bool profiling = false;
+    int profiling = 0;                        // 0 off, 1 stage timers, 2 + one event pair per k_syrk_lower launch
     StageTimer timers[NMGP_STAGE_COUNT];
 };
 
@@ -130,9 +140,10 @@ int nmgp_ensure_S(nmgp_ctx* c);
 // below the matrix are carried along by the custom path only (must be 0 for rocSOLVER).
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info);
 hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n);
-struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream
-    nmgp_ctx* c; int stage; hipEvent_t e0 = nullptr, e1 = nullptr;
+struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream (or on an explicit stream)
+    nmgp_ctx* c; int stage; hipStream_t stream; hipEvent_t e0 = nullptr, e1 = nullptr;
     NmgpStage(nmgp_ctx* ctx, int st);
+    NmgpStage(nmgp_ctx* ctx, int st, hipStream_t s, double work, double bytes);
     ~NmgpStage();
 };
 
@@ -159,6 +170,8 @@ struct NmgpStage {   // RAII HIP-event timer of one stage on the context's strea
     } while (0)
 
 // ---- kernel launchers (nmgp_kernels.hip) -------------------------------------------------------
+const SyrkHook* nmgp_syrk_hook(nmgp_ctx* c);
+
 namespace nmgpk {
 
 // parameter unpacking: ell = exp(tilde_l), Lv = tril factors with exp on the diagonal slots
@@ -253,6 +266,6 @@ void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n,
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
              long long vstride);
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
-                 int nb1, int* info, int batch, long long bstride, int istride);
+                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook = nullptr);
 
 }  // namespace nmgpk
