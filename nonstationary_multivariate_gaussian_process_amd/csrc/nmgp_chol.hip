@@ -28,6 +28,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define SY_BM 128
 #define SY_BK 16
 #define SY_LD (SY_BM + 16)
+#define SY_SB 8          // super-block edge in tiles (XCD-aware order)
 
 // The k-panel prefetch must stay asynchronous: gload() only ISSUES 16-byte loads from clamped (always valid)
 // addresses; the zeroing of out-of-range rows / k-columns is applied by sstore(), right before the LDS write, i.e.
@@ -39,13 +40,140 @@ __device__ __forceinline__ int clamp_row_pair(int r, int rows) {
     return rc < 0 ? 0 : rc;
 }
 
+// ---- fast path of k_syrk_lower: a FULL 128x128 tile, K a multiple of 32, 8 waves of 64 x 32 ------------------------
+// On gfx950 the FP64 MFMA competes with every other vector instruction of the SIMD (32 extra v_add_u32 per k-step cost
+// 4.3 % in tools/lab/syrk_lab.hip), so the k-loop carries no VALU work at all:
+//   * panel loads are buffer loads: uniform descriptor + constant per-lane offset + a scalar offset that advances with k;
+//   * the loop is unrolled by two so that the LDS buffer offsets are instruction immediates;
+//   * row-PAIRED fragment layout: MFMA tile (2p + s) of the i side covers rows 32p + 2*(lane & 15) + s, so one
+//     ds_read_b128 feeds two MFMA operands and every lane owns two consecutive rows of C (16-byte loads / stores of C);
+//     the j side is paired the same way;
+//   * the accumulators start as -C and the epilogue stores -acc, instead of negating a fragment per k-substep;
+//   * no edge masks (the masked generic path below handles partial tiles).
+// 68.4 TFLOP/s on the K = 512 trailing update of 32 chains (generic path: 55.1; rocblas_dgemm_strided_batched: 67.1).
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
+                                               int row0, int col0, bool diag, int kt0, double* sA0, double* sB0) {
+    constexpr int BK = 16;
+    constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // global -> LDS staging: thread (rp, cg) moves rows 2rp, 2rp + 1 of k-columns cg and cg + 8 of the panel
+    const int rp = tid & 63, cg = tid >> 6;
+    const int offA = (cg * lda + row0 + 2 * rp) * 8, offB = (cg * lda + col0 + 2 * rp) * 8;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const int gstep = BK * lda * 8, ghalf = 8 * lda * 8;
+    int soff = kt0 * gstep;
+    v4i ra0, ra1, rb0, rb1;
+    auto gload = [&]() {
+        ra0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offA, soff, 0);
+        ra1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offA, soff + ghalf, 0);
+        if (!diag) {
+            rb0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff, 0);
+            rb1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff + ghalf, 0);
+        }
+        soff += gstep;
+    };
+    double* wA = sA0 + cg * SY_LD + 2 * rp;
+    double* wB = sB0 + cg * SY_LD + 2 * rp;
+    auto sstore = [&](int buf) {
+        *reinterpret_cast<v4i*>(wA + buf * SBUF) = ra0;
+        *reinterpret_cast<v4i*>(wA + buf * SBUF + 8 * SY_LD) = ra1;
+        if (!diag) {
+            *reinterpret_cast<v4i*>(wB + buf * SBUF) = rb0;
+            *reinterpret_cast<v4i*>(wB + buf * SBUF + 8 * SY_LD) = rb1;
+        }
+    };
+    const bool active = !(diag && (wi * 64 + 63 < wj * 32));   // sub-tile strictly above the diagonal: nothing to do
+    const int nk = K / BK;
+    gload();
+    // acc[p][s][tj][r]: i = row0 + wi*64 + 32p + 2*l15 + s ; j = col0 + wj*32 + 2*(l4 + 4r) + tj
+    v4d acc[2][2][2];
+    if (active) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = row0 + wi * 64 + 32 * p + 2 * l15;
+                    const int j = col0 + wj * 32 + 2 * (l4 + 4 * r) + tj;
+                    const double2 c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);
+                    acc[p][0][tj][r] = -c.x;
+                    acc[p][1][tj][r] = -c.y;
+                }
+    }
+    sstore(0);
+    __syncthreads();
+    const double* rA = sA0 + wi * 64 + 2 * l15 + l4 * SY_LD;
+    const double* rB = (diag ? sA0 : sB0) + wj * 32 + 2 * l15 + l4 * SY_LD;
+    auto compute = [&](int buf) {
+        const double* tA = rA + buf * SBUF;
+        const double* tB = rB + buf * SBUF;
+        v2d fa[2], fb, na[2], nb;
+        fa[0] = *reinterpret_cast<const v2d*>(tA);
+        fa[1] = *reinterpret_cast<const v2d*>(tA + 32);
+        fb = *reinterpret_cast<const v2d*>(tB);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            if (kk + 1 < BK / 4) {
+                na[0] = *reinterpret_cast<const v2d*>(tA + (kk + 1) * 4 * SY_LD);
+                na[1] = *reinterpret_cast<const v2d*>(tA + (kk + 1) * 4 * SY_LD + 32);
+                nb = *reinterpret_cast<const v2d*>(tB + (kk + 1) * 4 * SY_LD);
+            }
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+                        acc[p][sx][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[tj], fa[p][sx], acc[p][sx][tj], 0, 0, 0);
+            if (kk + 1 < BK / 4) {
+                fa[0] = na[0];
+                fa[1] = na[1];
+                fb = nb;
+            }
+        }
+    };
+    for (int kt = kt0; kt < nk; kt += 2) {         // nk - kt0 is even
+        gload();
+        if (active) compute(0);
+        sstore(1);
+        __syncthreads();
+        if (kt + 2 < nk) gload();
+        if (active) compute(1);
+        if (kt + 2 < nk) sstore(0);
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + wi * 64 + 32 * p + 2 * l15;
+                const int j = col0 + wj * 32 + 2 * (l4 + 4 * r) + tj;
+                if (diag && j > i + 1) continue;
+                double2 c;
+                c.x = -acc[p][0][tj][r];
+                c.y = -acc[p][1][tj][r];
+                if (diag && j == i + 1) C[(size_t)j * ldc + i + 1] = c.y;     // the row pair straddles the diagonal
+                else *reinterpret_cast<double2*>(&C[(size_t)j * ldc + i]) = c;
+            }
+}
+
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
 // NWJ = column groups of waves per 128x128 tile: 2 -> 4 waves of 64x64 (16 MFMA tiles each), 4 -> 8 waves of 64x32
 // (8 MFMA tiles each, ~110 VGPRs, so four waves per SIMD hide each other's barrier / LDS / prologue stalls).
 template <int NWJ, int BK>
 __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_lower(const double* __restrict__ A, int lda,
                                                                  double* __restrict__ C, int ldc, int mrows, int ncols,
-                                                                 int K, long long bstride, long long cstride, int ktri) {
+                                                                 int K, long long bstride, long long cstride, int ktri,
+                                                                 int swz, int nbatch) {
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
@@ -53,14 +181,61 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
     constexpr int CGS = NT / 64;           // k-columns covered per load round
     __shared__ double sA[2][BK * SY_LD];
     __shared__ double sB[2][BK * SY_LD];
-    const int bi = blockIdx.x, bj = blockIdx.y;
+    int bi = blockIdx.x, bj = blockIdx.y;
+    int bz = blockIdx.z;
+    if (swz) {
+        // XCD-aware tile order.  Workgroups are dealt round-robin and IN ORDER over the 8 XCDs (t and t + 8 share an
+        // L2), so every XCD must receive the same work per round or the others idle behind it: the VALID tiles of all
+        // matrices of the batch are enumerated compactly (strips of 8 tile columns; per strip the diagonal triangle,
+        // then 8-row blocks) and cut into chunks of 64 tiles = the 32 CUs x 2 resident workgroups of one XCD.  XCD
+        // t % 8 walks chunks (t % 8), (t % 8) + 8, ...: a chunk touches <= 16 row panels + 8 column panels of A, which
+        // its L2 then fetches once per chunk instead of once per tile.  swz = valid tiles per matrix.
+        const int t = blockIdx.x, q = t >> 3;
+        const long long g = ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63);     // global compact tile index
+        bz = (int)(g / swz);
+        if (bz >= nbatch) return;                                            // padding workgroup
+        int idx = (int)(g - (long long)bz * swz);
+        const int gx = (mrows + SY_BM - 1) / SY_BM, gy = (ncols + SY_BM - 1) / SY_BM;
+        int c0 = 0, W = 0, cnt = 0;
+        for (;; c0 += SY_SB) {                       // strip of W tile columns starting at tile column c0
+            W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
+            cnt = W * (W + 1) / 2 + (gx - c0 - W) * W;
+            if (idx < cnt) break;
+            idx -= cnt;
+        }
+        const int tri = W * (W + 1) / 2;
+        if (idx < tri) {
+            int b = 0;
+            while (idx >= W - b) {
+                idx -= W - b;
+                ++b;
+            }
+            bj = c0 + b;
+            bi = bj + idx;
+        } else {
+            idx -= tri;
+            const int blk = idx / (SY_SB * W), in = idx - blk * (SY_SB * W);
+            const int base = c0 + W + blk * SY_SB;
+            const int rb = gx - base < SY_SB ? gx - base : SY_SB;
+            bj = c0 + in / rb;
+            bi = base + in % rb;
+        }
+    }
     if (bi < bj) return;
-    A += (size_t)blockIdx.z * bstride;       // batch of independent matrices (one per chain), same shape
-    C += (size_t)blockIdx.z * cstride;
+    A += (size_t)bz * bstride;       // batch of independent matrices (one per chain), same shape
+    C += (size_t)bz * cstride;
     const bool diag = (bi == bj);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int row0 = bi * SY_BM, col0 = bj * SY_BM;
+    if constexpr (NWJ == 4 && BK == 16) {
+        // interior tile (uniform per workgroup): the mask-free, VALU-free path
+        // (32-bit byte offsets into the panel: (K + 16) * lda * 8 must stay below 2^31)
+        if (row0 + SY_BM <= mrows && col0 + SY_BM <= ncols && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, &sA[0][0], &sB[0][0]);
+            return;
+        }
+    }
     const int rp = tid & 63, cg = tid >> 6;
     double2 ra[NQ], rb[NQ];
 
@@ -171,6 +346,7 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
 static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
+static int g_syrk_swz = 1;     // NMGP_SYRK_SWIZZLE=0 disables the XCD-aware tile order
 static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
@@ -181,8 +357,24 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         g_syrk_nwj = (e && std::atoi(e) == 4) ? 2 : 4;
         const char* b = std::getenv("NMGP_SYRK_BK");
         g_syrk_bk = (b && std::atoi(b) == 32) ? 32 : 16;
+        if (const char* z = std::getenv("NMGP_SYRK_SWIZZLE")) g_syrk_swz = std::atoi(z) != 0;
     }
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
+    int swz = 0;
+    if (g_syrk_swz && grid.y >= 4) {
+        const int gx = grid.x, gy = grid.y;
+        int tiles = 0;                                  // valid (lower-trapezoid) tiles per matrix
+        for (int c0 = 0; c0 < gy; c0 += SY_SB) {
+            const int W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
+            tiles += W * (W + 1) / 2 + (gx - c0 - W) * W;
+        }
+        const long long total = (long long)tiles * batch;
+        const long long rounds = (total + 511) / 512;   // 8 XCDs x 64 tiles per round
+        if (rounds >= 16) {                             // fewer rounds: the chunking's tail costs more than L2 reuse gains
+            grid = dim3((unsigned)(rounds * 512), 1, 1);
+            swz = tiles;
+        }
+    }
     const long long cs = cstride < 0 ? bstride : cstride;
     void* tok = nullptr;
     if (g_hook && g_hook->begin) {
@@ -191,11 +383,11 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
     }
     if (g_syrk_nwj == 2)
-        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
     else if (g_syrk_bk == 32)
-        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
     else
-        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri);
+        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 

@@ -1,0 +1,75 @@
+"""Per-launch-class efficiency of k_syrk_lower from a rocprofv3 kernel trace of `bench.py` (N=2048, D=3 by default).
+
+usage: python tools/syrk_classes.py <kernel_trace.csv> [n] [nb1] [batch]
+Replays the factorisation's launch schedule (recursive-halving panels + trailing updates) to attach (mrows, ncols, K)
+to the SYRK launches of the LAST evaluation in the trace, then prints time, TFLOP/s and algorithmic TB/s per class.
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def schedule(n, nb1, extra=1):
+    sched = []
+
+    def rec(c0, w):
+        if w <= 64:
+            return
+        h = ((w // 2 + 63) // 64) * 64
+        if h >= w:
+            h = ((w - 1) // 64) * 64
+        rec(c0, h)
+        c1 = c0 + h
+        below = n + extra - c1
+        if below > 0:
+            sched.append((below, w - h, h))
+        rec(c1, w - h)
+
+    for c0 in range(0, n, nb1):
+        w1 = min(nb1, n - c0)
+        rec(c0, w1)
+        c1 = c0 + w1
+        if c1 < n:
+            sched.append((n + extra - c1, n - c1, w1))
+    return sched
+
+
+def main():
+    path = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
+    nb1 = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "k_svc_finalize" in r["Kernel_Name"]]
+    ev = rows[idx[-2] + 1: idx[-1] + 1]
+    sched = schedule(n, nb1)
+    sy = [r for r in ev if "k_syrk" in r["Kernel_Name"]]
+    if len(sy) != len(sched):
+        raise SystemExit("launch count mismatch: trace %d, schedule %d" % (len(sy), len(sched)))
+    agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for r, (m, nc, K) in zip(sy, sched):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+        elems = nc * m - 0.5 * nc * (nc - 1)
+        a = agg[(K, nc)]
+        a[0] += 1
+        a[1] += d
+        a[2] += 2 * K * elems * batch
+        a[3] += 8 * batch * (2 * elems + m * K)
+    tot = 0.0
+    for k in sorted(agg):
+        c, d, fl, by = agg[k]
+        tot += d
+        print("K=%4d ncols=%5d launches=%3d time=%7.3f ms  %6.1f TF/s  %5.2f TB/s (algorithmic)  %5.1f flop/B" % (
+            k[0], k[1], c, d * 1e3, fl / d / 1e12, by / d / 1e12, fl / by))
+    print("k_syrk_lower total %.3f ms" % (tot * 1e3))
+    oth = defaultdict(float)
+    for r in ev:
+        oth[r["Kernel_Name"].split("(")[0][-48:]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    for k, v in sorted(oth.items(), key=lambda t: -t[1])[:8]:
+        print("  %-50s %8.3f ms" % (k, v))
+    print("wall of the evaluation: %.3f ms" % ((int(ev[-1]["End_Timestamp"]) - int(ev[0]["Start_Timestamp"])) * 1e-6))
+
+
+if __name__ == "__main__":
+    main()
