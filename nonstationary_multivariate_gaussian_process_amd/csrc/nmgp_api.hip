@@ -346,7 +346,8 @@ int nmgp_get_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor** out) {
 // events for the look-ahead factorisation (created once, reused by every evaluation)
 hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n) {
     if (!c->chol_lookahead) return nullptr;
-    const size_t need = 2 * (size_t)((n + c->chol_nb1 - 1) / c->chol_nb1) + 3;
+    const int nbmin = c->chol_nb1 > 0 ? c->chol_nb1 : 512;
+    const size_t need = 2 * (size_t)((n + nbmin - 1) / nbmin) + 3;
     while (c->chol_ev.size() < need) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;

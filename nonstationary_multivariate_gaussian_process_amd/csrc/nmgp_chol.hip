@@ -18,6 +18,7 @@
 //
 // All matrices column-major, lower triangle; leading dimensions must be even (16-byte vector loads).
 #include "nmgp_internal.h"
+#include <cstring>
 
 namespace nmgpk {
 
@@ -38,6 +39,105 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int clamp_row_pair(int r, int rows) {
     int rc = r < rows - 1 ? r : rows - 2;
     return rc < 0 ? 0 : rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
+// info receives (goff + c + 1) for the first non-positive pivot c (LAPACK convention), left untouched otherwise.
+// ---------------------------------------------------------------------------------------------
+// reciprocal of a positive double: v_rcp_f64 seed + two Newton steps (about 1 ulp; an IEEE division costs ~3x the
+// latency and sits on the critical path of every pivot)
+__device__ __forceinline__ double fast_recip(double p) {
+    double x = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-p, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+// One pivot column of the 64x64 block.  The block is kept UNSCALED: column c holds S[r][c] as it stands when the
+// column is finalised and the update is S[r][cc] -= S[r][c] S[cc][c] / S[c][c]; the division by sqrt(pivot) is applied
+// once at the end.  Critical path per column = barrier, LDS read, reciprocal, one multiply-add for the NEXT column,
+// LDS write: the next column is published before the remaining (register-only) updates of this column are done.
+template <int KC, int GC>
+__device__ __forceinline__ void potf2_step(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
+                                           int* __restrict__ info, int goff, int r, int g, int tid) {
+    constexpr int c = 4 * KC + GC;
+    constexpr int NKC = (GC == 3) ? KC + 1 : KC;          // register slot / owner class of column c + 1
+    constexpr int NGC = (GC == 3) ? 0 : GC + 1;
+    if (c >= nb) return;                                     // uniform
+    const double* cb = colbuf[c & 1];
+    const double piv = cb[c];
+    const double mine = cb[r];
+    double t[16];
+#pragma unroll
+    for (int kk = KC; kk < 16; ++kk) t[kk] = cb[4 * kk + g];
+    if (tid == 0) {
+        pivs[c] = piv;
+        if (!(piv > 0.0)) atomicCAS(info, 0, goff + c + 1);
+    }
+    const double pinv = fast_recip(piv);
+    const double f = mine * pinv;
+    if (c + 1 < 64) {
+        // next column first: update it, publish it, then the barrier that opens step c + 1
+        if (NKC < 16) {
+            const int cc = 4 * NKC + g;
+            const double upd = fma(-f, t[NKC < 16 ? NKC : 15], a[NKC < 16 ? NKC : 15]);
+            const bool on = (g == NGC) && (cc <= r);
+            if (NKC < 16) a[NKC < 16 ? NKC : 15] = on ? upd : a[NKC < 16 ? NKC : 15];
+            if (g == NGC) colbuf[(c + 1) & 1][r] = a[NKC < 16 ? NKC : 15];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kk = KC; kk < 16; ++kk) {
+        const int cc = 4 * kk + g;
+        const double upd = fma(-f, t[kk], a[kk]);
+        bool on = (kk > KC || g > GC) && (cc <= r);
+        if (kk == NKC) on = on && (g != NGC);               // already done above
+        a[kk] = on ? upd : a[kk];
+    }
+}
+
+template <int KC>
+__device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
+                                             int* __restrict__ info, int goff, int r, int g, int tid) {
+    potf2_step<KC, 0>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 1>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 2>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+    potf2_step<KC, 3>(a, colbuf, pivs, nb, info, goff, r, g, tid);
+}
+
+// The whole factorisation of one 64x64 block by the threads of a workgroup (256 or 512 of them: thread tid acts as
+// (r, g) = (tid & 63, (tid >> 6) & 3), so the upper half of a 512-thread workgroup repeats the lower half's work and
+// writes identical values).  colbuf / pivs: 3 x 64 doubles of LDS.
+__device__ __forceinline__ void potf2_body(double* __restrict__ A, int lda, int nb, int* __restrict__ info, int goff, int tid,
+                                           double (*colbuf)[64], double* pivs) {
+    // thread (r, g): row r, column class g (wave-uniform); it keeps S[r][4 kk + g], kk = 0..15, in registers.  Columns
+    // travel between the waves through a double-buffered LDS column.
+    const int r = tid & 63, g = (tid >> 6) & 3;
+    double a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int c = 4 * kk + g;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
+        a[kk] = v;
+    }
+    if (tid < 64) pivs[tid] = 1.0;
+    if (g == 0) colbuf[0][r] = a[0];
+    __syncthreads();
+#define PF(K) potf2_steps4<K>(a, colbuf, pivs, nb, info, goff, r, g, tid)
+    PF(0); PF(1); PF(2); PF(3); PF(4); PF(5); PF(6); PF(7); PF(8); PF(9); PF(10); PF(11); PF(12); PF(13); PF(14); PF(15);
+#undef PF
+    __syncthreads();
+    // scale column c by 1/sqrt(pivot_c): L[r][c] = S[r][c] / sqrt(S[c][c])  (diagonal: sqrt(pivot))
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int c = 4 * kk + g;
+        if (r < nb && c <= r) A[(size_t)c * lda + r] = a[kk] * rsqrt(pivs[c]);
+    }
 }
 
 // ---- fast path of k_syrk_lower: a FULL 128x128 tile, K a multiple of 32, 8 waves of 64 x 32 ------------------------
@@ -148,7 +248,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
         if (kt + 2 < nk) sstore(0);
         __syncthreads();
     }
-    if (!active) return;
+    if (active) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -164,16 +264,16 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                 if (diag && j == i + 1) C[(size_t)j * ldc + i + 1] = c.y;     // the row pair straddles the diagonal
                 else *reinterpret_cast<double2*>(&C[(size_t)j * ldc + i]) = c;
             }
+    }
 }
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
 // NWJ = column groups of waves per 128x128 tile: 2 -> 4 waves of 64x64 (16 MFMA tiles each), 4 -> 8 waves of 64x32
 // (8 MFMA tiles each, ~110 VGPRs, so four waves per SIMD hide each other's barrier / LDS / prologue stalls).
 template <int NWJ, int BK>
-__global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_lower(const double* __restrict__ A, int lda,
-                                                                 double* __restrict__ C, int ldc, int mrows, int ncols,
-                                                                 int K, long long bstride, long long cstride, int ktri,
-                                                                 int swz, int nbatch) {
+__device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int mrows,
+                                               int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
+                                               int nbatch) {
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
@@ -222,6 +322,11 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
         }
     }
     if (bi < bj) return;
+    // workgroup-uniform by construction; the 64-bit divisions of the decode run on the VALU, so tell the compiler
+    // (keeps the tile origin, the C pointer and the buffer descriptor in SGPRs)
+    bi = __builtin_amdgcn_readfirstlane(bi);
+    bj = __builtin_amdgcn_readfirstlane(bj);
+    bz = __builtin_amdgcn_readfirstlane(bz);
     A += (size_t)bz * bstride;       // batch of independent matrices (one per chain), same shape
     C += (size_t)bz * cstride;
     const bool diag = (bi == bj);
@@ -331,17 +436,50 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
         if (kt + 1 < nk) sstore(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
     }
-    if (!active) return;
+    if (active) {
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
+        for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+            for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
-                const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
-                if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
+                    const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
+                    if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
+                }
+    }
+}
+
+// C[i, j] -= sum_k A[i, k] A[j, k] on the lower trapezoid (see syrk_tile_body), plus an OPTIONAL fused diagonal step
+// (pnb > 0, NMGP_FUSE_POTF2=1; off by default, see potrf_lower): the leading 64x64 block of the updated C is the next
+// block the factorisation needs, so the workgroup that owned tile (0, 0) -- dispatched first -- can factor it right
+// here while the other tiles of the launch are still running.
+// The tail re-derives the tile from blockIdx instead of keeping it alive across the tile body (register pressure).
+template <int NWJ, int BK>
+__global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_lower(const double* __restrict__ A, int lda,
+                                                                 double* __restrict__ C, int ldc, int mrows, int ncols,
+                                                                 int K, long long bstride, long long cstride, int ktri,
+                                                                 int swz, int nbatch, int* __restrict__ pinfo, int pgoff,
+                                                                 int pnb, int pistride) {
+    syrk_tile_body<NWJ, BK>(A, lda, C, ldc, mrows, ncols, K, bstride, cstride, ktri, swz, nbatch);
+    if (pnb <= 0) return;
+    int bz;
+    if (swz) {
+        // tile (0, 0) of matrix bz is compact tile index g = bz * swz: g = (chunk * 64 + within), chunk = 8 (q >> 6) + (t & 7)
+        const int t = blockIdx.x, q = t >> 3;
+        const long long g = ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63);
+        bz = (int)(g / swz);
+        if (bz >= nbatch || g != (long long)bz * swz) return;
+    } else {
+        if (blockIdx.x != 0 || blockIdx.y != 0) return;
+        bz = blockIdx.z;
+    }
+    bz = __builtin_amdgcn_readfirstlane(bz);
+    __shared__ double colbuf[2][64];
+    __shared__ double pivs[64];
+    __threadfence();
+    __syncthreads();
+    potf2_body(C + (size_t)bz * cstride, ldc, pnb, pinfo + (size_t)bz * pistride, pgoff, threadIdx.x, colbuf, pivs);
 }
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
@@ -349,8 +487,18 @@ static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects 
 static int g_syrk_swz = 1;     // NMGP_SYRK_SWIZZLE=0 disables the XCD-aware tile order
 static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
+// fused-potf2 state of the factorisation in progress (set by potrf_lower)
+struct PotfFuse {
+    bool on = false;
+    int* info = nullptr;
+    int istride = 0;
+    int n = 0;
+    int done_at = -1;        // global column whose diagonal block the last SYRK launch has already factored
+};
+static thread_local PotfFuse g_fuse;
+
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride, int ktri) {
+                long long bstride, long long cstride, int ktri, int next_c) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
     if (g_syrk_nwj == 0) {
         const char* e = std::getenv("NMGP_SYRK_WAVES");
@@ -376,6 +524,14 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         }
     }
     const long long cs = cstride < 0 ? bstride : cstride;
+    int* pinfo = nullptr;
+    int pnb = 0;
+    if (g_fuse.on && next_c >= 0 && next_c < g_fuse.n) {
+        pinfo = g_fuse.info;
+        pnb = g_fuse.n - next_c < 64 ? g_fuse.n - next_c : 64;
+        if (pnb > ncols) pnb = 0;                 // (cannot happen in the schedules below; keeps the kernel's contract)
+        else g_fuse.done_at = next_c;
+    }
     void* tok = nullptr;
     if (g_hook && g_hook->begin) {
         // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
@@ -383,118 +539,25 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
     }
     if (g_syrk_nwj == 2)
-        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
+        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     else if (g_syrk_bk == 32)
-        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
+        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     else
-        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch);
+        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// 64x64 diagonal block: unblocked right-looking Cholesky in LDS, one barrier per column.
-// info receives (goff + c + 1) for the first non-positive pivot c (LAPACK convention), left untouched otherwise.
-// ---------------------------------------------------------------------------------------------
-// reciprocal of a positive double: v_rcp_f64 seed + two Newton steps (about 1 ulp; an IEEE division costs ~3x the
-// latency and sits on the critical path of every pivot)
-__device__ __forceinline__ double fast_recip(double p) {
-    double x = __builtin_amdgcn_rcp(p);
-    double e = fma(-p, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-p, x, 1.0);
-    x = fma(x, e, x);
-    return x;
-}
-
-// One pivot column of the 64x64 block.  The block is kept UNSCALED: column c holds S[r][c] as it stands when the
-// column is finalised and the update is S[r][cc] -= S[r][c] S[cc][c] / S[c][c]; the division by sqrt(pivot) is applied
-// once at the end.  Critical path per column = barrier, LDS read, reciprocal, one multiply-add for the NEXT column,
-// LDS write: the next column is published before the remaining (register-only) updates of this column are done.
-template <int KC, int GC>
-__device__ __forceinline__ void potf2_step(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
-                                           int* __restrict__ info, int goff, int r, int g, int tid) {
-    constexpr int c = 4 * KC + GC;
-    constexpr int NKC = (GC == 3) ? KC + 1 : KC;          // register slot / owner class of column c + 1
-    constexpr int NGC = (GC == 3) ? 0 : GC + 1;
-    if (c >= nb) return;                                     // uniform
-    const double* cb = colbuf[c & 1];
-    const double piv = cb[c];
-    const double mine = cb[r];
-    double t[16];
-#pragma unroll
-    for (int kk = KC; kk < 16; ++kk) t[kk] = cb[4 * kk + g];
-    if (tid == 0) {
-        pivs[c] = piv;
-        if (!(piv > 0.0)) atomicCAS(info, 0, goff + c + 1);
-    }
-    const double pinv = fast_recip(piv);
-    const double f = mine * pinv;
-    if (c + 1 < 64) {
-        // next column first: update it, publish it, then the barrier that opens step c + 1
-        if (NKC < 16) {
-            const int cc = 4 * NKC + g;
-            const double upd = fma(-f, t[NKC < 16 ? NKC : 15], a[NKC < 16 ? NKC : 15]);
-            const bool on = (g == NGC) && (cc <= r);
-            if (NKC < 16) a[NKC < 16 ? NKC : 15] = on ? upd : a[NKC < 16 ? NKC : 15];
-            if (g == NGC) colbuf[(c + 1) & 1][r] = a[NKC < 16 ? NKC : 15];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int kk = KC; kk < 16; ++kk) {
-        const int cc = 4 * kk + g;
-        const double upd = fma(-f, t[kk], a[kk]);
-        bool on = (kk > KC || g > GC) && (cc <= r);
-        if (kk == NKC) on = on && (g != NGC);               // already done above
-        a[kk] = on ? upd : a[kk];
-    }
-}
-
-template <int KC>
-__device__ __forceinline__ void potf2_steps4(double (&a)[16], double (*colbuf)[64], double* pivs, int nb,
-                                             int* __restrict__ info, int goff, int r, int g, int tid) {
-    potf2_step<KC, 0>(a, colbuf, pivs, nb, info, goff, r, g, tid);
-    potf2_step<KC, 1>(a, colbuf, pivs, nb, info, goff, r, g, tid);
-    potf2_step<KC, 2>(a, colbuf, pivs, nb, info, goff, r, g, tid);
-    potf2_step<KC, 3>(a, colbuf, pivs, nb, info, goff, r, g, tid);
-}
-
 __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
                                                    int goff, long long bstride, int istride) {
-    A += (size_t)blockIdx.x * bstride;
-    info += (size_t)blockIdx.x * istride;
-    // thread (r, g): row r = tid & 63, column class g = tid >> 6 (wave-uniform); it keeps S[r][4 kk + g], kk = 0..15,
-    // in registers.  Columns travel between the waves through a double-buffered LDS column.
     __shared__ double colbuf[2][64];
     __shared__ double pivs[64];
-    const int tid = threadIdx.x;
-    const int r = tid & 63, g = tid >> 6;
-    double a[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int c = 4 * kk + g;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
-        a[kk] = v;
-    }
-    if (tid < 64) pivs[tid] = 1.0;
-    if (g == 0) colbuf[0][r] = a[0];
-    __syncthreads();
-#define PF(K) potf2_steps4<K>(a, colbuf, pivs, nb, info, goff, r, g, tid)
-    PF(0); PF(1); PF(2); PF(3); PF(4); PF(5); PF(6); PF(7); PF(8); PF(9); PF(10); PF(11); PF(12); PF(13); PF(14); PF(15);
-#undef PF
-    __syncthreads();
-    // scale column c by 1/sqrt(pivot_c): L[r][c] = S[r][c] / sqrt(S[c][c])  (diagonal: sqrt(pivot))
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int c = 4 * kk + g;
-        if (r < nb && c <= r) A[(size_t)c * lda + r] = a[kk] * rsqrt(pivs[c]);
-    }
+    potf2_body(A + (size_t)blockIdx.x * bstride, lda, nb, info + (size_t)blockIdx.x * istride, goff, threadIdx.x, colbuf, pivs);
 }
 
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride) {
+    if (g_fuse.on && g_fuse.done_at == goff) return;      // already factored by the tile (0, 0) of the previous update
     hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
 }
 
@@ -585,10 +648,136 @@ __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// panel solve on the matrix cores.  The VALU substitution above spends ~550 FP64 FMAs + LDS reads per lane and, on
+// gfx950, FP64 VALU work and FP64 MFMAs share the SIMD: k_trsm_64 ran at 2.4 TB/s.  Here the 64 columns are split
+// into four 16-column blocks:  X_q = (A_q - sum_{p<q} X_p L_qp^T) inv(L_qq)^T  with every product a chain of
+// v_mfma_f64_16x16x4_f64.  The workgroup first inverts the four 16x16 diagonal blocks of L (one wave each, 16 lanes,
+// forward substitution on the identity) and lays -L_qp and inv(L_qq) out in LDS in MFMA A-operand order.  The
+// accumulator layout of one product (lane: matrix row l & 15, columns (l >> 4) + 4 reg) IS the B-operand layout of
+// the next one (k-slice reg), so the rows stay in registers from load to store.
+// A workgroup (4 waves) handles 128 rows, a wave two interleaved 16-row chunks (rows 2(l & 15) + s: 16-byte accesses).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, int ldl, int nb, double* __restrict__ A,
+                                                   int lda, int rows, long long bstride) {
+    L += (size_t)blockIdx.y * bstride;
+    A += (size_t)blockIdx.y * bstride;
+    __shared__ double Lm[64][65];
+    __shared__ double Linv[4][16][17];
+    __shared__ double ops[10][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int rbase = blockIdx.x * 128 + w * 32 + 2 * l15;       // rows rbase, rbase + 1
+    const bool v0 = rbase < rows, v1 = rbase + 1 < rows;
+    // this wave's rows: issued first, so that their latency hides under the factor preparation
+    v4d T[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * q + 4 * r + l4;
+            double2 v = make_double2(0.0, 0.0);
+            if (v0 && col < nb) v = *reinterpret_cast<const double2*>(&A[(size_t)col * lda + rbase]);
+            T[0][q][r] = v.x;
+            T[1][q][r] = v1 ? v.y : 0.0;
+        }
+    {
+        double lv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = tid + 256 * q;
+            const int r = idx & 63, c = idx >> 6;
+            double v = (r == c) ? 1.0 : 0.0;
+            if (r < nb && c <= r) v = L[(size_t)c * ldl + r];
+            lv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx = tid + 256 * q;
+            Lm[idx & 63][idx >> 6] = lv[q];
+        }
+    }
+    __syncthreads();
+    if (lane < 16) {
+        // wave w inverts diagonal block w: lane j carries column j of the inverse (forward substitution on e_j)
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc = fma(-Lm[16 * w + i][16 * w + k], x[k], sacc);
+            x[i] = sacc / Lm[16 * w + i][16 * w + i];
+            Linv[w][i][lane] = x[i];
+        }
+    }
+    __syncthreads();
+    // A-operand order: ops[blk][kk][l] = M[row = l & 15][k = 4 kk + (l >> 4)]; blk 0..5 = -L_qp (q = 1: p0; q = 2: p0, p1;
+    // q = 3: p0, p1, p2), blk 6 + q = inv(L_qq)
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        const int idx = tid + 256 * e;               // 0 .. 2559
+        const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+        const int rr = l & 15, kc = 4 * kk + (l >> 4);
+        double v;
+        if (blk < 6) {
+            const int q = blk == 0 ? 1 : (blk < 3 ? 2 : 3);
+            const int pp = blk == 0 ? 0 : (blk < 3 ? blk - 1 : blk - 3);
+            v = -Lm[16 * q + rr][16 * pp + kc];
+        } else {
+            v = (kc <= rr) ? Linv[blk - 6][rr][kc] : 0.0;
+        }
+        ops[blk][kk][l] = v;
+    }
+    __syncthreads();
+    // wave-uniform exit only: the MFMAs below need every lane of the wave active (A-operand rows live in all 64 lanes)
+    if (blockIdx.x * 128 + w * 32 >= rows) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int pp = 0; pp < q; ++pp) {
+            const int blk = (q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double a = ops[blk][kk][lane];
+                T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][pp][kk], T[0][q], 0, 0, 0);
+                T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][pp][kk], T[1][q], 0, 0, 0);
+            }
+        }
+        v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = ops[6 + q][kk][lane];
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][q][kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][q][kk], x1, 0, 0, 0);
+        }
+        T[0][q] = x0;
+        T[1][q] = x1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * q + 4 * r + l4;
+            if (col < nb) {
+                if (v1) *reinterpret_cast<double2*>(&A[(size_t)col * lda + rbase]) = make_double2(T[0][q][r], T[1][q][r]);
+                else if (v0) A[(size_t)col * lda + rbase] = T[0][q][r];
+            }
+        }
+}
+
+static int g_trsm_valu = -1;     // NMGP_TRSM=valu selects the substitution kernel (k_trsm_64)
+
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
              long long bstride) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
+    if (g_trsm_valu < 0) {
+        const char* e = std::getenv("NMGP_TRSM");
+        g_trsm_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+    }
+    if (g_trsm_valu)
+        hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
+    else
+        hipLaunchKernelGGL(k_trsm_64m, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
 }
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
@@ -636,7 +825,7 @@ static void factor_panel_rl(hipStream_t s, double* A, int lda, int n, int extra,
             const int ncols = c0 + w1 - (j0 + jb);
             if (ncols > 0)
                 syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1,
-                           0);
+                           0, j0 + jb);
         }
     }
 }
@@ -656,7 +845,7 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
     const int c1 = c0 + h;
     const int below = active_rows(n, extra, xtri, c1) - c1;
     if (below > 0)
-        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0, c1);
     factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
 }
 
@@ -688,9 +877,29 @@ struct HookScope {
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
                  int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook) {
     HookScope hs(hook);
+    // auto panel width: 1024 halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
+    // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, slower for one chain
+    if (nb1 <= 0) nb1 = (batch >= 4 && n >= 4096) ? 1024 : 512;
     const int is = istride;
     const long long bs = bstride;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
+    // NMGP_FUSE_POTF2=1: factor the next diagonal block inside the preceding update's tile (0, 0).  Off by default: next
+    // to MFMA-saturated tiles the VALU-bound block factorisation runs ~3.5x slower (90 us), which the many short
+    // panel-internal launches cannot hide (measured 602 vs 634 evals/s at 32 chains, 137 vs 143 for one chain).
+    static const bool fuse_env = [] {
+        const char* e = std::getenv("NMGP_FUSE_POTF2");
+        return e && std::atoi(e) != 0;
+    }();
+    struct FuseScope {
+        PotfFuse prev;
+        FuseScope() : prev(g_fuse) {}
+        ~FuseScope() { g_fuse = prev; }
+    } fs;
+    g_fuse.on = fuse_env && !la;
+    g_fuse.info = info;
+    g_fuse.istride = is;
+    g_fuse.n = n;
+    g_fuse.done_at = -1;
     if (!la) {
         for (int c0 = 0; c0 < n; c0 += nb1) {
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
@@ -698,7 +907,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
             const int c1 = c0 + w1;
             if (c1 < n)
                 syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda,
-                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0);
+                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0, c1);
         }
         return;
     }

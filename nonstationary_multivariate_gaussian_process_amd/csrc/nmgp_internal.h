@@ -125,7 +125,7 @@ struct nmgp_ctx {
     int last_kind = 0;          // 1 svc
 
     int chol_algo = 1;          // 0 = rocSOLVER dpotrf + rocBLAS dtrsv, 1 = custom blocked factorisation (nmgp_chol.hip)
-    int chol_nb1 = 512;         // outer panel width of the custom factorisation
+    int chol_nb1 = 0;           // outer panel width of the custom factorisation; 0 = auto (1024 for batches of large matrices, else 512)
     int profiling = 0;                        // 0 off, 1 stage timers, 2 + one event pair per k_syrk_lower launch
     StageTimer timers[NMGP_STAGE_COUNT];
 };
@@ -255,7 +255,7 @@ int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double*
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride = -1, int ktri = 0);
+                long long bstride, long long cstride = -1, int ktri = 0, int next_c = -1);
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch = 1, long long bstride = 0);
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride);
