@@ -358,7 +358,8 @@ hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n) {
 
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info) {
     if (c->chol_algo == 1 && (ld % 2 == 0)) {
-        potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0, nmgp_syrk_hook(c));
+        // used for the cached prior covariances, the dense-MVN primitive and prediction: accuracy before speed
+        potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, n), A, ld, n, extra, 0, c->chol_nb1, d_info, 1, 0, 0, nmgp_syrk_hook(c), 1);
         return 0;
     }
     if (extra != 0) return nmgp_fail(c, NMGP_E_STATE, "rocSOLVER path cannot carry extra rows");
@@ -668,7 +669,7 @@ static int get_batch_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor**
     hipMemsetAsync(info, 0, B * sizeof(int), c->stream);
     rbf_cov_sym(c->stream, c->b_x, c->N, alpha, beta, pf.L, pf.ld, false, (int)B);
     potrf_lower(c->stream, c->stream2, nmgp_chol_events(c, c->N), pf.L, pf.ld, c->N, 0, 0, c->chol_nb1, info, (int)B,
-                (long long)pf.ld * N, 1, nmgp_syrk_hook(c));
+                (long long)pf.ld * N, 1, nmgp_syrk_hook(c), 1);
     half_logdet(c->stream, pf.L, pf.ld, c->N, pf.logdet, (int)B);
     std::vector<int> hi(B);
     hipMemcpyAsync(hi.data(), info, B * sizeof(int), hipMemcpyDeviceToHost, c->stream);

@@ -555,10 +555,198 @@ __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int ld
     potf2_body(A + (size_t)blockIdx.x * bstride, lda, nb, info + (size_t)blockIdx.x * istride, goff, threadIdx.x, colbuf, pivs);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64x64 diagonal block, blocked: four 16-column blocks.  The 64 sequential pivots of k_potf2_64 cost ~960 cycles each
+// (a workgroup barrier, ~10 LDS reads and ~16 masked FMAs per thread and pivot); here only the 16x16 DIAGONAL blocks
+// are factored pivot by pivot -- by ONE wave (no s_barrier; a wave's LDS operations execute in order), 4 columns per
+// lane -- and everything below / right of them goes through the matrix cores:
+//   (A) wave 0: unscaled right-looking factorisation of S_qq; the same row operations applied to the identity give the
+//       unit-lower inverse E (S = L~ D L~^T, E = L~^-1), so inv(L_qq) = D^-1/2 E comes along off the critical path;
+//   (B) X_i = S_iq inv(L_qq)^T for the row blocks below (wave w takes block q + 1 + w; 4 MFMAs each);
+//   (C) S_ij -= X_i X_j^T for q < j <= i (at most 6 tiles of 4 MFMAs over the 4 waves).
+// The block lives in LDS column-major (S[col][row]); every MFMA operand is a plain 8-byte read of it.
+// ---------------------------------------------------------------------------------------------
+#define PB_LD 66
+template <int KC, int GC>
+__device__ __forceinline__ void potf2b_step(double (&a)[4], double (&e)[4], double (*colbuf)[16], double (*rowbuf)[16],
+                                            double* pivs, double* Sqq, int q, int* __restrict__ info, int goff, int r, int g,
+                                            int lane) {
+    constexpr int c = 4 * KC + GC;
+    constexpr int NKC = (GC == 3) ? KC + 1 : KC;          // register slot / owner class of column c + 1
+    constexpr int NGC = (GC == 3) ? 0 : GC + 1;
+    const double* cb = colbuf[c & 1];
+    const double* rb = rowbuf[c & 1];
+    const double piv = cb[c];
+    const double mine = cb[r];
+    double t[4], er[4];
+#pragma unroll
+    for (int kk = KC; kk < 4; ++kk) t[kk] = cb[4 * kk + g];
+#pragma unroll
+    for (int kk = 0; kk <= KC; ++kk) er[kk] = rb[4 * kk + g];
+    const double pinv = fast_recip(piv);
+    const double f = (r > c) ? mine * pinv : 0.0;          // rows up to the pivot row are final
+    // S[r][cc] -= f S[cc][c].  No column masks: column c is final and leaves for LDS right below, so the slots of
+    // columns <= c are dead values from here on and may be clobbered.
+#pragma unroll
+    for (int kk = KC; kk < 4; ++kk) a[kk] = fma(-f, t[kk], a[kk]);
+    // E[r][cc] -= f E[c][cc]: row c of E is zero right of column c, so no mask here either
+#pragma unroll
+    for (int kk = 0; kk <= KC; ++kk) e[kk] = fma(-f, er[kk], e[kk]);
+    if (c + 1 < 16) {
+        if (g == NGC) colbuf[(c + 1) & 1][r] = a[NKC < 4 ? NKC : 3];
+        if (r == c + 1) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) rowbuf[(c + 1) & 1][4 * kk + g] = e[kk];
+        }
+    }
+    // off the critical path: the finished (unscaled) column c goes back to the block, the pivot to pivs
+    if (g == GC) Sqq[c * PB_LD + r] = mine;
+    if (lane == 0) {
+        pivs[16 * q + c] = piv;
+        if (!(piv > 0.0)) atomicCAS(info, 0, goff + 16 * q + c + 1);
+    }
+    __builtin_amdgcn_wave_barrier();                        // keep the LDS writes ahead of the next step's reads
+}
+
+template <int KC>
+__device__ __forceinline__ void potf2b_steps4(double (&a)[4], double (&e)[4], double (*colbuf)[16], double (*rowbuf)[16],
+                                              double* pivs, double* Sqq, int q, int* __restrict__ info, int goff, int r,
+                                              int g, int lane) {
+    potf2b_step<KC, 0>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2b_step<KC, 1>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2b_step<KC, 2>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2b_step<KC, 3>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+}
+
+__global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
+                                                    int goff, long long bstride, int istride) {
+    A += (size_t)blockIdx.x * bstride;
+    info += (size_t)blockIdx.x * istride;
+    __shared__ double S[64 * PB_LD];            // S[col * PB_LD + row]
+    __shared__ double Einv[4][16][17];          // inv(L_qq)[row][col] of the four diagonal blocks
+    __shared__ double colbuf[2][16];
+    __shared__ double rowbuf[2][16];
+    __shared__ double pivs[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = tid + 256 * k;
+        const int r = idx & 63, c = idx >> 6;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
+        S[c * PB_LD + r] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        if (w == 0) {
+            // (A) thread (r, g) = (lane & 15, lane >> 4) keeps S_qq[r][4 kk + g] and E[r][4 kk + g], kk = 0..3
+            const int r = l15, g = l4;
+            double a[4], e[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cc = 4 * kk + g;
+                a[kk] = (cc <= r) ? S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
+                e[kk] = (cc == r) ? 1.0 : 0.0;
+            }
+            if (g == 0) colbuf[0][r] = a[0];
+            if (r == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) rowbuf[0][4 * kk + g] = e[kk];
+            }
+            __builtin_amdgcn_wave_barrier();
+            double* Sqq = &S[(16 * q) * PB_LD + 16 * q];
+            potf2b_steps4<0>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<1>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<2>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<3>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+            // L_qq = S~ D^-1/2 (column scaling of the unscaled columns the steps left in S), inv(L_qq) = D^-1/2 E (rows)
+            const double sr = rsqrt(pivs[16 * q + r]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cc = 4 * kk + g;
+                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(pivs[16 * q + cc]);
+                Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (q == 3) break;
+        // (B) X_i = S_iq inv(L_qq)^T, row block i = q + 1 + w
+        {
+            const int i = q + 1 + w;
+            if (i < 4) {
+                v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = Einv[q][l15][4 * kk + l4];                                   // A: row c' = l15, k = c
+                    const double bv = S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];            // B: k = c, col = row r
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+                }
+                // all four k-slices are read before any of them is overwritten (same wave, in order)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) S[(16 * q + l4 + 4 * reg) * PB_LD + 16 * i + l15] = x[reg];
+            }
+        }
+        __syncthreads();
+        // (C) S_ij -= X_i X_j^T for q < j <= i <= 3; tile t of this step goes to wave t % 4
+        {
+            int t = 0;
+            for (int i = q + 1; i < 4; ++i)
+                for (int j = q + 1; j <= i; ++j, ++t) {
+                    if ((t & 3) != w) continue;
+                    v4d acc;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[reg] = S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double av = -S[(16 * q + 4 * kk + l4) * PB_LD + 16 * j + l15];      // A: row of X_j
+                        const double bv = S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];       // B: row of X_i
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15] = acc[reg];
+                }
+        }
+        __syncthreads();
+    }
+    // L goes to the lower triangle; the STRICT UPPER part of each diagonal 16x16 block (never read by a lower-triangular
+    // consumer) receives inv(L_qq) transposed, which k_trsm_64m picks up instead of inverting the blocks again
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = tid + 256 * k;
+        const int r = idx & 63, c = idx >> 6;
+        if (r < nb && c < nb) {
+            if (c <= r) A[(size_t)c * lda + r] = S[c * PB_LD + r];
+            else if ((c >> 4) == (r >> 4)) A[(size_t)c * lda + r] = Einv[c >> 4][c & 15][r & 15];
+        }
+    }
+}
+
+static int g_potf2_valu = -1;     // NMGP_POTF2=valu selects the unblocked kernel (k_potf2_64)
+// set by potrf_lower(precise = 1): substitution-based panel kernels (no inverted 16x16 blocks) for the ill-conditioned,
+// cached prior covariances (RBF + 1e-6 I, condition number up to 1e11), where the inverse-based solves cost parity digits
+static thread_local int g_precise = 0;
+
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride) {
     if (g_fuse.on && g_fuse.done_at == goff) return;      // already factored by the tile (0, 0) of the previous update
-    hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
+    if (g_potf2_valu < 0) {
+        const char* e = std::getenv("NMGP_POTF2");
+        g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+    }
+    if (g_potf2_valu || g_precise)
+        hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
+    else
+        hipLaunchKernelGGL(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
+}
+
+static int g_potf2_exports_inv() {
+    if (g_potf2_valu < 0) {
+        const char* e = std::getenv("NMGP_POTF2");
+        g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+    }
+    return (g_potf2_valu || g_precise || g_fuse.on) ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,7 +847,7 @@ __global__ __launch_bounds__(256) void k_trsm_64(const double* __restrict__ L, i
 // A workgroup (4 waves) handles 128 rows, a wave two interleaved 16-row chunks (rows 2(l & 15) + s: 16-byte accesses).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, int ldl, int nb, double* __restrict__ A,
-                                                   int lda, int rows, long long bstride) {
+                                                   int lda, int rows, long long bstride, int have_inv, int reps) {
     L += (size_t)blockIdx.y * bstride;
     A += (size_t)blockIdx.y * bstride;
     __shared__ double Lm[64][65];
@@ -667,20 +855,25 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
     __shared__ double ops[10][4][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int rbase = blockIdx.x * 128 + w * 32 + 2 * l15;       // rows rbase, rbase + 1
-    const bool v0 = rbase < rows, v1 = rbase + 1 < rows;
-    // this wave's rows: issued first, so that their latency hides under the factor preparation
+    // the workgroup handles `reps` groups of 128 rows (the factor preparation is paid once); wave w of group it owns rows
+    // rbase, rbase + 1 with rbase = (blockIdx.x * reps + it) * 128 + 32 w + 2 (lane & 15)
+    int rbase = blockIdx.x * reps * 128 + w * 32 + 2 * l15;
     v4d T[2][4];
+    auto load_rows = [&]() {
+        const bool v0 = rbase < rows, v1 = rbase + 1 < rows;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = 16 * q + 4 * r + l4;
-            double2 v = make_double2(0.0, 0.0);
-            if (v0 && col < nb) v = *reinterpret_cast<const double2*>(&A[(size_t)col * lda + rbase]);
-            T[0][q][r] = v.x;
-            T[1][q][r] = v1 ? v.y : 0.0;
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * q + 4 * r + l4;
+                double2 v = make_double2(0.0, 0.0);
+                if (v0 && col < nb) v = *reinterpret_cast<const double2*>(&A[(size_t)col * lda + rbase]);
+                T[0][q][r] = v.x;
+                T[1][q][r] = v1 ? v.y : 0.0;
+            }
+    };
+    // the first group's rows are issued first, so that their latency hides under the factor preparation
+    load_rows();
     {
         double lv[16];
 #pragma unroll
@@ -688,7 +881,8 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
             const int idx = tid + 256 * q;
             const int r = idx & 63, c = idx >> 6;
             double v = (r == c) ? 1.0 : 0.0;
-            if (r < nb && c <= r) v = L[(size_t)c * ldl + r];
+            // have_inv: the strict upper part of the diagonal 16x16 blocks holds inv(L_qq)^T (written by k_potf2_64b)
+            if (r < nb && c < nb && (c <= r || (have_inv && (c >> 4) == (r >> 4)))) v = L[(size_t)c * ldl + r];
             lv[q] = v;
         }
 #pragma unroll
@@ -698,7 +892,18 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
         }
     }
     __syncthreads();
-    if (lane < 16) {
+    if (have_inv) {
+        // inv(L_qq)[i][j] (i > j) sits at Lm[16 q + j][16 q + i]; the diagonal is 1 / L_ii
+        const int qq = tid >> 6, i = (tid >> 2) & 15, j0 = (tid & 3) * 4;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj;
+            double v = 0.0;
+            if (j < i) v = Lm[16 * qq + j][16 * qq + i];
+            else if (j == i) v = 1.0 / Lm[16 * qq + i][16 * qq + i];
+            Linv[qq][i][j] = v;
+        }
+    } else if (lane < 16) {
         // wave w inverts diagonal block w: lane j carries column j of the inverse (forward substitution on e_j)
         double x[16];
 #pragma unroll
@@ -729,43 +934,49 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
         ops[blk][kk][l] = v;
     }
     __syncthreads();
-    // wave-uniform exit only: the MFMAs below need every lane of the wave active (A-operand rows live in all 64 lanes)
-    if (blockIdx.x * 128 + w * 32 >= rows) return;
+    for (int it = 0; it < reps; ++it) {
+        // wave-uniform exit only: the MFMAs below need every lane of the wave active (A-operand rows live in all 64 lanes)
+        if ((blockIdx.x * reps + it) * 128 + w * 32 >= rows) return;
+        if (it > 0) load_rows();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int pp = 0; pp < q; ++pp) {
-            const int blk = (q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp;
+            for (int pp = 0; pp < q; ++pp) {
+                const int blk = (q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = ops[blk][kk][lane];
+                    T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][pp][kk], T[0][q], 0, 0, 0);
+                    T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][pp][kk], T[1][q], 0, 0, 0);
+                }
+            }
+            v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const double a = ops[blk][kk][lane];
-                T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][pp][kk], T[0][q], 0, 0, 0);
-                T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][pp][kk], T[1][q], 0, 0, 0);
+                const double a = ops[6 + q][kk][lane];
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][q][kk], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][q][kk], x1, 0, 0, 0);
             }
+            T[0][q] = x0;
+            T[1][q] = x1;
         }
-        v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+        const bool v0 = rbase < rows, v1 = rbase + 1 < rows;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const double a = ops[6 + q][kk][lane];
-            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][q][kk], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][q][kk], x1, 0, 0, 0);
-        }
-        T[0][q] = x0;
-        T[1][q] = x1;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * q + 4 * r + l4;
+                if (col < nb) {
+                    if (v1) *reinterpret_cast<double2*>(&A[(size_t)col * lda + rbase]) = make_double2(T[0][q][r], T[1][q][r]);
+                    else if (v0) A[(size_t)col * lda + rbase] = T[0][q][r];
+                }
+            }
+        rbase += 128;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = 16 * q + 4 * r + l4;
-            if (col < nb) {
-                if (v1) *reinterpret_cast<double2*>(&A[(size_t)col * lda + rbase]) = make_double2(T[0][q][r], T[1][q][r]);
-                else if (v0) A[(size_t)col * lda + rbase] = T[0][q][r];
-            }
-        }
 }
 
 static int g_trsm_valu = -1;     // NMGP_TRSM=valu selects the substitution kernel (k_trsm_64)
+static int g_potf2_exports_inv();  // 1 when the block factorisation in use leaves inv(L_qq) in the diagonal blocks
 
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
              long long bstride) {
@@ -774,10 +985,17 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
         const char* e = std::getenv("NMGP_TRSM");
         g_trsm_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
     }
-    if (g_trsm_valu)
+    if (g_trsm_valu || g_precise)
         hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
     else
-        hipLaunchKernelGGL(k_trsm_64m, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
+    {
+        // groups of 128 rows per workgroup: more of them amortise the factor preparation once the launch would fill the
+        // chip (512 resident workgroups) several times over anyway
+        const long long wgs = (long long)cdiv_c(rows, 128) * batch;
+        const int reps = wgs >= 4096 ? 4 : (wgs >= 2048 ? 2 : 1);
+        hipLaunchKernelGGL(k_trsm_64m, dim3(cdiv_c(rows, 128 * reps), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride,
+                           g_potf2_exports_inv(), reps);
+    }
 }
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
@@ -875,8 +1093,13 @@ struct HookScope {
 };
 
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
-                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook) {
+                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook, int precise) {
     HookScope hs(hook);
+    struct PreciseScope {
+        int prev;
+        explicit PreciseScope(int p) : prev(g_precise) { g_precise = p; }
+        ~PreciseScope() { g_precise = prev; }
+    } ps(precise);
     // auto panel width: 1024 halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
     // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, slower for one chain
     if (nb1 <= 0) nb1 = (batch >= 4 && n >= 4096) ? 1024 : 512;

@@ -266,6 +266,7 @@ void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n,
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
              long long vstride);
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
-                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook = nullptr);
+                 int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook = nullptr,
+                 int precise = 0);
 
 }  // namespace nmgpk
