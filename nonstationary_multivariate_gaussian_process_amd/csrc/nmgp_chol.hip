@@ -155,7 +155,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
-                                               int row0, int col0, bool diag, int kt0, double* sA0, double* sB0) {
+                                               int row0, int col0, bool diag, int kt0, bool beta0, double* sA0,
+                                               double* sB0) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -201,7 +202,8 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                 for (int r = 0; r < 4; ++r) {
                     const int i = row0 + wi * 64 + 32 * p + 2 * l15;
                     const int j = col0 + wj * 32 + 2 * (l4 + 4 * r) + tj;
-                    const double2 c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);
+                    double2 c = make_double2(0.0, 0.0);
+                    if (!beta0) c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);     // uniform branch
                     acc[p][0][tj][r] = -c.x;
                     acc[p][1][tj][r] = -c.y;
                 }
@@ -337,7 +339,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         // interior tile (uniform per workgroup): the mask-free, VALU-free path
         // (32-bit byte offsets into the panel: (K + 16) * lda * 8 must stay below 2^31)
         if (row0 + SY_BM <= mrows && col0 + SY_BM <= ncols && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
-            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, &sA[0][0], &sB[0][0]);
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, &sA[0][0], &sB[0][0]);
             return;
         }
     }
@@ -380,7 +382,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     const bool active = !(diag && (wi * 64 + 63 < wj * CW));
     const int nk = (K + BK - 1) / BK;
     // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
-    // first row contribute nothing
+    // first row contribute nothing; ktri also means beta = 0: C is OVERWRITTEN with -A A^T (no zero-fill, no read of C)
     const int kt0 = ktri ? (row0 / BK) : 0;
     gload(kt0 * BK);
     // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
@@ -395,7 +397,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
                 const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
-                acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
+                acc[tj][ti][r] = (!ktri && active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
     sstore(0, kt0 * BK);
     __syncthreads();

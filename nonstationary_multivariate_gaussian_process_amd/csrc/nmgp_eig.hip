@@ -317,7 +317,6 @@ int kron_chol_loglik(nmgp_ctx* c, EigWork& w, double sigma2, bool want_grad, dou
         const double one = 1.0, zero = 0.0;
         BLAS_TRY(c, rocblas_dgemv_strided_batched(c->blas, rocblas_operation_none, N, N, &one, S + xoff, ld, bs, z, 1, N,
                                                   &zero, alpha, 1, N, M));                       // alpha_p = X_p z_p
-        HIP_TRY(c, hipMemsetAsync(Cneg, 0, (size_t)M * N * N * sizeof(double), s));
         syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, M, bs, (long long)N * N, 1);              // -S_p^-1
     }
     double* part;
