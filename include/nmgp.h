@@ -158,7 +158,8 @@ int nmgp_kron_inv_logdet(nmgp_ctx* ctx, double sigma2, const double* B, int M, c
 /* Cholesky factorisation A = L L^T of a symmetric positive definite [n,n] matrix (torch.cholesky as used at
  * prediction.py:974; also the entry through which the custom blocked factorisation of the log-posterior path is
  * tested on its own).  out_L: [n,n] row-major with the factor in the UPPER triangle == column-major lower (i.e.
- * out_L^T is the usual lower factor; the other triangle holds the input's values).  rhs (optional, [n]) is carried
+ * out_L^T is the usual lower factor; the other triangle is scratch: the input's values, except that the diagonal 16x16
+ * blocks carry the inverted diagonal blocks the panel solve reuses).  rhs (optional, [n]) is carried
  * through the factorisation as an extra row: out_z = L^-1 rhs.  algo: 1 = custom gfx950 factorisation, 0 = rocSOLVER. */
 int nmgp_cholesky(nmgp_ctx* ctx, const double* A, int n, const double* rhs, double* out_L, double* out_z,
                   int algo);

@@ -155,8 +155,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
-                                               int row0, int col0, bool diag, int kt0, bool beta0, double* sA0,
-                                               double* sB0) {
+                                               int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
+                                               double* sA0, double* sB0) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -168,13 +168,28 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     const int gstep = BK * lda * 8, ghalf = 8 * lda * 8;
     int soff = kt0 * gstep;
+    // THE RIGHT-HAND-SIDE ROW (has_y): the single extra row `yrow` below the full tiles would cost a whole masked tile
+    // per tile column.  Instead the two waves of a DIAGONAL tile whose sub-tile lies above the diagonal (wi = 0, wj = 2, 3)
+    // update it: C[yrow, col0 .. col0+127] -= A[yrow, :] A[col0 .. col0+127, :]^T, 64 columns per wave, with the tile's own
+    // j-side panel (already in LDS) as the MFMA A operand and a 16-row chunk holding the y row in its row 0 as B operand:
+    // 16 MFMAs per k-step in waves that would otherwise idle through the 32 of their siblings.
+    const bool has_y = diag && yrow >= 0;
+    const bool ywave = has_y && wi == 0 && wj >= 2;
+    const int offY = ((tid & 15) * lda + yrow) * 8;
+    double* sY = sB0;                              // a diagonal tile stages no B panel: its LDS holds the y k-panels
     v4i ra0, ra1, rb0, rb1;
+    double ry = 0.0;
     auto gload = [&]() {
         ra0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offA, soff, 0);
         ra1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offA, soff + ghalf, 0);
         if (!diag) {
             rb0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff, 0);
             rb1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff + ghalf, 0);
+        }
+        if (has_y && tid < 16) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i t2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, offY, soff, 0);
+            ry = __builtin_bit_cast(double, t2);
         }
         soff += gstep;
     };
@@ -187,8 +202,11 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
             *reinterpret_cast<v4i*>(wB + buf * SBUF) = rb0;
             *reinterpret_cast<v4i*>(wB + buf * SBUF + 8 * SY_LD) = rb1;
         }
+        if (has_y && tid < 16) sY[buf * 16 + tid] = ry;
     };
-    const bool active = !(diag && (wi * 64 + 63 < wj * 32));   // sub-tile strictly above the diagonal: nothing to do
+    // sub-tile strictly above the diagonal, or right of a half-width tile (ncw = 64: the j-side rows 64..127 of the staged
+    // panel are real rows of A, just not columns of this update): nothing to do
+    const bool active = !(diag && (wi * 64 + 63 < wj * 32)) && (wj * 32 < ncw);
     const int nk = K / BK;
     gload();
     // acc[p][s][tj][r]: i = row0 + wi*64 + 32p + 2*l15 + s ; j = col0 + wj*32 + 2*(l4 + 4r) + tj
@@ -206,6 +224,18 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                     if (!beta0) c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);     // uniform branch
                     acc[p][0][tj][r] = -c.x;
                     acc[p][1][tj][r] = -c.y;
+                }
+    }
+    // y accumulators of a y-wave live in acc[u][0][t]: columns j = col0 + 64 (wj - 2) + 32 u + 2 (l4 + 4 r) + t, lanes l15 = 0
+    if (ywave) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = col0 + 64 * (wj - 2) + 32 * u + 2 * (l4 + 4 * r) + t;
+                    acc[u][0][t][r] = (l15 == 0) ? -C[(size_t)j * ldc + yrow] : 0.0;
                 }
     }
     sstore(0);
@@ -240,15 +270,44 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
             }
         }
     };
+    const double* rY = sA0 + 64 * (wj - 2) + 2 * l15 + l4 * SY_LD;      // j-side rows of a y-wave (only used by y-waves)
+    auto compute_y = [&](int buf) {
+        const double* tB = rY + buf * SBUF;
+        const double* ty = sY + buf * 16 + l4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const v2d f0 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD);
+            const v2d f1 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD + 32);
+            const double yv = ty[4 * kk];
+            const double fy = (l15 == 0) ? yv : 0.0;
+            acc[0][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[0], fy, acc[0][0][0], 0, 0, 0);
+            acc[0][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[1], fy, acc[0][0][1], 0, 0, 0);
+            acc[1][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[0], fy, acc[1][0][0], 0, 0, 0);
+            acc[1][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[1], fy, acc[1][0][1], 0, 0, 0);
+        }
+    };
     for (int kt = kt0; kt < nk; kt += 2) {         // nk - kt0 is even
         gload();
         if (active) compute(0);
+        else if (ywave) compute_y(0);
         sstore(1);
         __syncthreads();
         if (kt + 2 < nk) gload();
         if (active) compute(1);
+        else if (ywave) compute_y(1);
         if (kt + 2 < nk) sstore(0);
         __syncthreads();
+    }
+    if (ywave && l15 == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = col0 + 64 * (wj - 2) + 32 * u + 2 * (l4 + 4 * r) + t;
+                    C[(size_t)j * ldc + yrow] = -acc[u][0][t][r];
+                }
     }
     if (active) {
 #pragma unroll
@@ -276,6 +335,9 @@ template <int NWJ, int BK>
 __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int mrows,
                                                int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
                                                int nbatch) {
+    const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
+    const int yrow = (ktri & 4) ? mrows : -1; // row `mrows` (just below the full tiles) is the right-hand-side row: see syrk_tile_fast
+    ktri &= 1;
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
@@ -338,8 +400,11 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     if constexpr (NWJ == 4 && BK == 16) {
         // interior tile (uniform per workgroup): the mask-free, VALU-free path
         // (32-bit byte offsets into the panel: (K + 16) * lda * 8 must stay below 2^31)
-        if (row0 + SY_BM <= mrows && col0 + SY_BM <= ncols && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
-            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, &sA[0][0], &sB[0][0]);
+        // (a tile that is full in rows and 64 columns wide -- the K = 64 updates inside a panel -- also qualifies)
+        const int ncw = ncols - col0 >= SY_BM ? SY_BM : ncols - col0;
+        if (row0 + SY_BM <= mrows && (ncw == SY_BM || (ncw == 64 && !nohalf)) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
+            (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, &sA[0][0], &sB[0][0]);
             return;
         }
     }
@@ -487,6 +552,8 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
 static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
 static int g_syrk_swz = 1;     // NMGP_SYRK_SWIZZLE=0 disables the XCD-aware tile order
+static int g_syrk_half = 1;    // NMGP_SYRK_HALF=0: see syrk_tile_body
+static int g_syrk_yrow = 1;    // NMGP_SYRK_YROW=0: the right-hand-side row keeps its own (masked) tile row
 static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
 // fused-potf2 state of the factorisation in progress (set by potrf_lower)
@@ -508,7 +575,18 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         const char* b = std::getenv("NMGP_SYRK_BK");
         g_syrk_bk = (b && std::atoi(b) == 32) ? 32 : 16;
         if (const char* z = std::getenv("NMGP_SYRK_SWIZZLE")) g_syrk_swz = std::atoi(z) != 0;
+        if (const char* z = std::getenv("NMGP_SYRK_HALF")) g_syrk_half = std::atoi(z) != 0;
+        if (const char* z = std::getenv("NMGP_SYRK_YROW")) g_syrk_yrow = std::atoi(z) != 0;
     }
+    // value evaluations carry ONE extra row (the right-hand side) below a whole number of tiles: the diagonal tiles take
+    // it along (syrk_tile_fast) and the masked tile row disappears.  Needs every tile of the launch on the fast path.
+    int yflag = 0;
+    if (g_syrk_yrow && g_syrk_nwj == 4 && g_syrk_bk == 16 && !ktri && mrows > SY_BM && (mrows - 1) % SY_BM == 0 &&
+        ncols % SY_BM == 0 && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL && (lda & 1) == 0 && (ldc & 1) == 0) {
+        yflag = 4;
+        mrows -= 1;
+    }
+    const int mrows_alg = mrows + (yflag ? 1 : 0);      // rows of the update as the caller stated it (work accounting)
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
     int swz = 0;
     if (g_syrk_swz && grid.y >= 4) {
@@ -534,18 +612,19 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         if (pnb > ncols) pnb = 0;                 // (cannot happen in the schedules below; keeps the kernel's contract)
         else g_fuse.done_at = next_c;
     }
+    const int kflags = (ktri ? 1 : 0) | (g_syrk_half ? 0 : 2) | yflag;
     void* tok = nullptr;
     if (g_hook && g_hook->begin) {
         // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
-        const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
-        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
+        const double elems = (double)ncols * mrows_alg - 0.5 * (double)ncols * (ncols - 1);
+        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows_alg * K));
     }
     if (g_syrk_nwj == 2)
-        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
+        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     else if (g_syrk_bk == 32)
-        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
+        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     else
-        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, ktri, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
+        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 

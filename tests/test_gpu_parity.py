@@ -444,3 +444,24 @@ def test_multi_subject_batch_matches_per_subject_evaluations(ctx):
         single, gsingle = ctx.logpos_svc(pars[k], hv, prior=True, want_grad=True)
         assert relerr(out[k][1], single[1]) < 1e-11 and relerr(out[k], single) < 1e-8, (k, out[k], single)
         assert vec_relerr(grads[k], gsingle) < 1e-8
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cond", [1e4, 1e8, 1e11])
+def test_custom_cholesky_backward_error_on_ill_conditioned_matrices(ctx, cond):
+    """The matrix-core panel kernels multiply by inverted 16x16 diagonal blocks (k_potf2_64b / k_trsm_64m): the
+    factorisation must stay backward stable, i.e. ||L L^T - A|| / ||A|| at rounding level whatever the conditioning."""
+    n = 333                                          # 5 blocks of 64 + a ragged one of 13
+    rng = np.random.default_rng(int(np.log10(cond)))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    w = np.logspace(0, -np.log10(cond), n)
+    A = (Q * w) @ Q.T
+    A = 0.5 * (A + A.T)
+    L = ctx.cholesky(A, None, algo=1)
+    res = np.abs(L @ L.T - A).max() / np.abs(A).max()
+    Lref = np.linalg.cholesky(A)
+    ref = np.abs(Lref @ Lref.T - A).max() / np.abs(A).max()
+    assert res < 50 * np.finfo(float).eps * n ** 0.5, (cond, res, ref)
+    assert res < 20 * max(ref, np.finfo(float).eps), (cond, res, ref)
+
+
+
