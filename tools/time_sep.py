@@ -7,7 +7,8 @@ for (N,M) in [(1024,5),(2048,5),(4096,5)]:
     pars=sim.perturb(d["pars_true"],0.05,0.4)
     hv=[sim.HYPER_SEP[k] for k in ["mu_tilde_l","alpha_tilde_l","beta_tilde_l","mu_tilde_sigma","alpha_tilde_sigma","beta_tilde_sigma","a","b","c"]]
     ctx.set_data(d["x"],d["Y"])
-    ctx.logpos_sep(pars,hv,True,True); ctx.logpos_sep(pars,hv,True,False)   # warm both modes (scratch sizes, prior factors)
+    for _ in range(2):   # warm both modes twice (scratch sizes, cached prior factors, rocBLAS kernel loading)
+        ctx.logpos_sep(pars,hv,True,True); ctx.logpos_sep(pars,hv,True,False)
     ctx.profile_enable(True); ctx.profile_reset()
     t0=time.perf_counter(); 
     for _ in range(3): out,_=ctx.logpos_sep(pars,hv,True,False)
