@@ -354,11 +354,15 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         // then 8-row blocks) and cut into chunks of 64 tiles = the 32 CUs x 2 resident workgroups of one XCD.  XCD
         // t % 8 walks chunks (t % 8), (t % 8) + 8, ...: a chunk touches <= 16 row panels + 8 column panels of A, which
         // its L2 then fetches once per chunk instead of once per tile.  swz = valid tiles per matrix.
+        // Short launches (swz < 0, -swz = valid tiles per matrix) keep the compact enumeration but deal consecutive
+        // tiles to consecutive XCDs: no early-exit workgroups, and no correlation between XCD and tile row (with a plain
+        // grid of 8 k tile rows XCD x owned tile row x: 1 tile for XCD 0, 8 for XCD 7).
         const int t = blockIdx.x, q = t >> 3;
-        const long long g = ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63);     // global compact tile index
-        bz = (int)(g / swz);
+        const int tiles_pm = swz > 0 ? swz : -swz;
+        const long long g = swz > 0 ? ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63) : (long long)t;   // compact tile index
+        bz = (int)(g / tiles_pm);
         if (bz >= nbatch) return;                                            // padding workgroup
-        int idx = (int)(g - (long long)bz * swz);
+        int idx = (int)(g - (long long)bz * tiles_pm);
         const int gx = (mrows + SY_BM - 1) / SY_BM, gy = (ncols + SY_BM - 1) / SY_BM;
         int c0 = 0, W = 0, cnt = 0;
         for (;; c0 += SY_SB) {                       // strip of W tile columns starting at tile column c0
@@ -534,9 +538,10 @@ __global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_l
     if (swz) {
         // tile (0, 0) of matrix bz is compact tile index g = bz * swz: g = (chunk * 64 + within), chunk = 8 (q >> 6) + (t & 7)
         const int t = blockIdx.x, q = t >> 3;
-        const long long g = ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63);
-        bz = (int)(g / swz);
-        if (bz >= nbatch || g != (long long)bz * swz) return;
+        const int tiles_pm = swz > 0 ? swz : -swz;
+        const long long g = swz > 0 ? ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63) : (long long)t;
+        bz = (int)(g / tiles_pm);
+        if (bz >= nbatch || g != (long long)bz * tiles_pm) return;
     } else {
         if (blockIdx.x != 0 || blockIdx.y != 0) return;
         bz = blockIdx.z;
@@ -589,7 +594,7 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
     const int mrows_alg = mrows + (yflag ? 1 : 0);      // rows of the update as the caller stated it (work accounting)
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
     int swz = 0;
-    if (g_syrk_swz && grid.y >= 4) {
+    if (g_syrk_swz && grid.y >= 2) {
         const int gx = grid.x, gy = grid.y;
         int tiles = 0;                                  // valid (lower-trapezoid) tiles per matrix
         for (int c0 = 0; c0 < gy; c0 += SY_SB) {
@@ -598,9 +603,12 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         }
         const long long total = (long long)tiles * batch;
         const long long rounds = (total + 511) / 512;   // 8 XCDs x 64 tiles per round
-        if (rounds >= 16) {                             // fewer rounds: the chunking's tail costs more than L2 reuse gains
+        if (rounds >= 16) {                             // chunks of 64 tiles per XCD (L2 reuse)
             grid = dim3((unsigned)(rounds * 512), 1, 1);
             swz = tiles;
+        } else {                                        // fewer rounds: the chunking's tail would cost more than it gains
+            grid = dim3((unsigned)total, 1, 1);
+            swz = -tiles;
         }
     }
     const long long cs = cstride < 0 ? bstride : cstride;
