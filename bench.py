@@ -120,6 +120,8 @@ def main():
         ctx.svc_eval_resident(hv, True, want_grad)
         return ctx.svc_fetch(False)[0]
 
+    # stage timers on from the warm-up on: their HIP events are created on first use, which must not fall into the timed region
+    ctx.profile_enable(True)
     for _ in range(a.warmup):
         out = step()
 
@@ -130,7 +132,6 @@ def main():
         for cg in ctxs:
             cg.sync()
 
-    ctx.profile_enable(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()

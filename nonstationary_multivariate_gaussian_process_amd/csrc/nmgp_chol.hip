@@ -1190,8 +1190,9 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         ~PreciseScope() { g_precise = prev; }
     } ps(precise);
     // auto panel width: 1024 halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
-    // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, slower for one chain
-    if (nb1 <= 0) nb1 = (batch >= 4 && n >= 4096) ? 1024 : 512;
+    // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, +2 % for 64 subjects of
+    // n = 3072, slower for one chain or 8 subjects
+    if (nb1 <= 0) nb1 = ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
     const int is = istride;
     const long long bs = bstride;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
