@@ -156,7 +156,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
                                                int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
-                                               double* sA0, double* sB0) {
+                                               int nyr, double* sA0, double* sB0) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -168,14 +168,15 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     const int gstep = BK * lda * 8, ghalf = 8 * lda * 8;
     int soff = kt0 * gstep;
-    // THE RIGHT-HAND-SIDE ROW (has_y): the single extra row `yrow` below the full tiles would cost a whole masked tile
-    // per tile column.  Instead the two waves of a DIAGONAL tile whose sub-tile lies above the diagonal (wi = 0, wj = 2, 3)
-    // update it: C[yrow, col0 .. col0+127] -= A[yrow, :] A[col0 .. col0+127, :]^T, 64 columns per wave, with the tile's own
-    // j-side panel (already in LDS) as the MFMA A operand and a 16-row chunk holding the y row in its row 0 as B operand:
-    // 16 MFMAs per k-step in waves that would otherwise idle through the 32 of their siblings.
+    // THE ROWS BELOW THE LAST FULL TILE (has_y): nyr <= 16 extra rows starting at `yrow` -- the right-hand-side row of a
+    // value evaluation, the last two rows of a gradient evaluation -- would cost a whole masked tile per tile column.
+    // Instead the two waves of a DIAGONAL tile whose sub-tile lies above the diagonal (wi = 0, wj = 2, 3) update them:
+    // C[yrow.., col0 .. col0+127] -= A[yrow.., :] A[col0 .. col0+127, :]^T, 64 columns per wave, with the tile's own j-side
+    // panel (already in LDS) as the MFMA A operand and a 16-row chunk holding the extra rows as B operand: 16 MFMAs per
+    // k-step in waves that would otherwise idle through the 32 of their siblings.
     const bool has_y = diag && yrow >= 0;
     const bool ywave = has_y && wi == 0 && wj >= 2;
-    const int offY = ((tid & 15) * lda + yrow) * 8;
+    const int offY = ((tid & 15) * lda + yrow + (tid >> 4)) * 8;      // thread (k = tid & 15, extra row tid >> 4)
     double* sY = sB0;                              // a diagonal tile stages no B panel: its LDS holds the y k-panels
     v4i ra0, ra1, rb0, rb1;
     double ry = 0.0;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
             rb0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff, 0);
             rb1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offB, soff + ghalf, 0);
         }
-        if (has_y && tid < 16) {
+        if (has_y && tid < 16 * nyr) {
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i t2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, offY, soff, 0);
             ry = __builtin_bit_cast(double, t2);
@@ -202,7 +203,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
             *reinterpret_cast<v4i*>(wB + buf * SBUF) = rb0;
             *reinterpret_cast<v4i*>(wB + buf * SBUF + 8 * SY_LD) = rb1;
         }
-        if (has_y && tid < 16) sY[buf * 16 + tid] = ry;
+        if (has_y && tid < 16 * nyr) sY[buf * 256 + tid] = ry;         // sY[buf][row][k]
     };
     // sub-tile strictly above the diagonal, or right of a half-width tile (ncw = 64: the j-side rows 64..127 of the staged
     // panel are real rows of A, just not columns of this update): nothing to do
@@ -226,7 +227,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                     acc[p][1][tj][r] = -c.y;
                 }
     }
-    // y accumulators of a y-wave live in acc[u][0][t]: columns j = col0 + 64 (wj - 2) + 32 u + 2 (l4 + 4 r) + t, lanes l15 = 0
+    // accumulators of a y-wave live in acc[u][0][t]: columns j = col0 + 64 (wj - 2) + 32 u + 2 (l4 + 4 r) + t, extra row l15
     if (ywave) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -235,7 +236,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = col0 + 64 * (wj - 2) + 32 * u + 2 * (l4 + 4 * r) + t;
-                    acc[u][0][t][r] = (l15 == 0) ? -C[(size_t)j * ldc + yrow] : 0.0;
+                    acc[u][0][t][r] = (l15 < nyr) ? -C[(size_t)j * ldc + yrow + l15] : 0.0;
                 }
     }
     sstore(0);
@@ -273,13 +274,13 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     const double* rY = sA0 + 64 * (wj - 2) + 2 * l15 + l4 * SY_LD;      // j-side rows of a y-wave (only used by y-waves)
     auto compute_y = [&](int buf) {
         const double* tB = rY + buf * SBUF;
-        const double* ty = sY + buf * 16 + l4;
+        const double* ty = sY + buf * 256 + l15 * 16 + l4;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const v2d f0 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD);
             const v2d f1 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD + 32);
             const double yv = ty[4 * kk];
-            const double fy = (l15 == 0) ? yv : 0.0;
+            const double fy = (l15 < nyr) ? yv : 0.0;
             acc[0][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[0], fy, acc[0][0][0], 0, 0, 0);
             acc[0][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[1], fy, acc[0][0][1], 0, 0, 0);
             acc[1][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[0], fy, acc[1][0][0], 0, 0, 0);
@@ -298,7 +299,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
         if (kt + 2 < nk) sstore(0);
         __syncthreads();
     }
-    if (ywave && l15 == 0) {
+    if (ywave && l15 < nyr) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -306,7 +307,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = col0 + 64 * (wj - 2) + 32 * u + 2 * (l4 + 4 * r) + t;
-                    C[(size_t)j * ldc + yrow] = -acc[u][0][t][r];
+                    C[(size_t)j * ldc + yrow + l15] = -acc[u][0][t][r];
                 }
     }
     if (active) {
@@ -336,7 +337,8 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
                                                int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
                                                int nbatch) {
     const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
-    const int yrow = (ktri & 4) ? mrows : -1; // row `mrows` (just below the full tiles) is the right-hand-side row: see syrk_tile_fast
+    const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
+    const int yrow = nyr ? mrows : -1;
     ktri &= 1;
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
@@ -408,7 +410,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         const int ncw = ncols - col0 >= SY_BM ? SY_BM : ncols - col0;
         if (row0 + SY_BM <= mrows && (ncw == SY_BM || (ncw == 64 && !nohalf)) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
             (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
-            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, &sA[0][0], &sB[0][0]);
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0]);
             return;
         }
     }
@@ -583,15 +585,17 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         if (const char* z = std::getenv("NMGP_SYRK_HALF")) g_syrk_half = std::atoi(z) != 0;
         if (const char* z = std::getenv("NMGP_SYRK_YROW")) g_syrk_yrow = std::atoi(z) != 0;
     }
-    // value evaluations carry ONE extra row (the right-hand side) below a whole number of tiles: the diagonal tiles take
-    // it along (syrk_tile_fast) and the masked tile row disappears.  Needs every tile of the launch on the fast path.
+    // evaluations carry a few extra rows below a whole number of tiles (value: the right-hand side; gradient: two more rows
+    // of L^-T): the diagonal tiles take them along (syrk_tile_fast) and the masked tile row disappears.  Needs every tile
+    // of the launch on the fast path.
     int yflag = 0;
-    if (g_syrk_yrow && g_syrk_nwj == 4 && g_syrk_bk == 16 && !ktri && mrows > SY_BM && (mrows - 1) % SY_BM == 0 &&
+    const int mrows_alg = mrows;                        // rows of the update as the caller stated it (work accounting)
+    const int nyr = mrows % SY_BM;                      // rows below the last full tile
+    if (g_syrk_yrow && g_syrk_nwj == 4 && g_syrk_bk == 16 && !ktri && mrows > SY_BM && nyr >= 1 && nyr <= 16 &&
         ncols % SY_BM == 0 && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL && (lda & 1) == 0 && (ldc & 1) == 0) {
-        yflag = 4;
-        mrows -= 1;
+        yflag = nyr << 2;
+        mrows -= nyr;
     }
-    const int mrows_alg = mrows + (yflag ? 1 : 0);      // rows of the update as the caller stated it (work accounting)
     dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
     int swz = 0;
     if (g_syrk_swz && grid.y >= 2) {
