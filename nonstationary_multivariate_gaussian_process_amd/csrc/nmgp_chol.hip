@@ -1193,10 +1193,11 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         explicit PreciseScope(int p) : prev(g_precise) { g_precise = p; }
         ~PreciseScope() { g_precise = prev; }
     } ps(precise);
-    // auto panel width: 1024 halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
+    // auto panel width (512 / 1024 / 2048; 64 chains of n = 6144: 673 / 716 / 728 evals/s): a wider panel halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
     // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, +2 % for 64 subjects of
-    // n = 3072, slower for one chain or 8 subjects
-    if (nb1 <= 0) nb1 = ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
+    // n = 3072, slower for one chain or 8 subjects; 2048 loses 3 % when the L^-T rows ride along (gradient)
+    if (nb1 <= 0)
+        nb1 = (batch >= 16 && n >= 6144 && xtri == 0) ? 2048 : ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
     const int is = istride;
     const long long bs = bstride;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
