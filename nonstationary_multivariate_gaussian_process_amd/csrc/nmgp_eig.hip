@@ -357,7 +357,9 @@ int kron_chol_adjoint(nmgp_ctx* c, EigWork& w, CholKron& ck, const double* d_ell
         fill_lower_to_full(s, C, N, N);
         sep_adjoint(s, c->d_x, d_ell, d_sig, ck.alpha, w.wB, M, C, N, part);
         sep_grad_sum(s, part, NJ, N, d_g);
-        // Xi' = U^T (K U): the M x M quadratic forms alpha_p^T K alpha_p'
+        // Xi' = U^T (K U): the M x M quadratic forms alpha_p^T K alpha_p'  (W is scratch: zeroed, so that a beta = 0 that is
+        // implemented as a scaling cannot carry stale NaNs over)
+        HIP_TRY(c, hipMemsetAsync(W, 0, ((size_t)N * M + (size_t)M * M) * sizeof(double), s));
         BLAS_TRY(c, rocblas_dsymm(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, c->d_K, N, ck.alpha, N, &zero,
                                   W, N));
         BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, ck.alpha, N,
