@@ -105,7 +105,19 @@ int nmgp_dev_alloc(nmgp_ctx* c, double** p, size_t nelem) {
         return nmgp_fail(c, NMGP_E_NOMEM, "hipMalloc of %zu bytes failed: %s", nelem * sizeof(double),
                          hipGetErrorString(e));
     }
+    if (nmgp_poison()) hipMemsetAsync(*p, 0xFF, nelem * sizeof(double), c->stream);
     return 0;
+}
+
+// NMGP_POISON=1 (debugging aid, exercised by tests/test_gpu_variants.py): every fresh device buffer and every scratch
+// hand-out is filled with NaNs (0xFF bytes) first, so that a kernel or library call that reads memory nobody wrote shows
+// up as a NaN in the result instead of depending on what the allocator happens to return.
+bool nmgp_poison() {
+    static const bool on = [] {
+        const char* e = std::getenv("NMGP_POISON");
+        return e && std::atoi(e) != 0;
+    }();
+    return on;
 }
 
 int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
@@ -113,6 +125,8 @@ int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
     if (b.cap < nelem || !b.p) {
         NMGP_TRY(nmgp_dev_alloc(c, &b.p, nelem));
         b.cap = nelem;
+    } else if (nmgp_poison()) {
+        hipMemsetAsync(b.p, 0xFF, nelem * sizeof(double), c->stream);
     }
     *out = b.p;
     return 0;

@@ -139,6 +139,7 @@ int nmgp_ensure_S(nmgp_ctx* c);
 // Cholesky of the n x n lower triangle (custom gfx950 factorisation or rocSOLVER, per ctx->chol_algo); `extra` rows
 // below the matrix are carried along by the custom path only (must be 0 for rocSOLVER).
 int nmgp_chol_factor(nmgp_ctx* c, double* A, int ld, int n, int extra, int* d_info);
+bool nmgp_poison();
 hipEvent_t* nmgp_chol_events(nmgp_ctx* c, int n);
 struct NmgpStage {   // RAII HIP-event timer of one stage on the context's stream (or on an explicit stream)
     nmgp_ctx* c; int stage; hipStream_t stream; hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -230,10 +230,12 @@ __global__ __launch_bounds__(256) void k_sep_adjoint(const double* __restrict__ 
         sl[tid] = (j < N) ? ell[j] : 1.0;
         ss[tid] = (j < N) ? sig[j] : 1.0;
     }
-    for (int k = tid; k < TJ * M; k += 256) {
-        int jj = k / M, p = k % M;
+    // every slot of sU is written: the contraction below runs over all NMGP_MAX_OUTPUTS slots with Ui[p] = 0 for p >= M,
+    // and 0 * (whatever a previous kernel left in LDS, possibly a NaN) is not 0
+    for (int k = tid; k < TJ * NMGP_MAX_OUTPUTS; k += 256) {
+        int jj = k / NMGP_MAX_OUTPUTS, p = k % NMGP_MAX_OUTPUTS;
         int j = j0 + jj;
-        sU[jj * NMGP_MAX_OUTPUTS + p] = (j < N) ? U[(size_t)p * N + j] : 0.0;
+        sU[k] = (j < N && p < M) ? U[(size_t)p * N + j] : 0.0;
     }
     __syncthreads();
     const int i = I * 64 + lane;

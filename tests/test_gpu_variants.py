@@ -36,7 +36,8 @@ print(json.dumps({"out": list(map(float, out)), "grad": list(map(float, grad)), 
 
 VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
             {"NMGP_SYRK_YROW": "0"}, {"NMGP_SYRK_HALF": "0"}, {"NMGP_SYRK_SWIZZLE": "0"}, {"NMGP_SYRK_WAVES": "4"},
-            {"NMGP_FUSE_POTF2": "1"}, {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"}]
+            {"NMGP_FUSE_POTF2": "1"}, {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"},
+            {"NMGP_POISON": "1"}]
 
 
 def run_variant(env_extra):
@@ -61,3 +62,14 @@ def test_kernel_variants_agree_with_the_default_configuration():
         assert relerr(np.array(r["out"]), np.array(ref["out"])) < 1e-7, env_extra
         assert vec_relerr(np.array(r["grad"]), np.array(ref["grad"])) < 1e-7, env_extra
         assert relerr(np.array(r["batch"]), np.array(ref["batch"])) < 1e-7, env_extra
+
+
+def test_parity_suite_passes_with_nan_poisoned_device_buffers():
+    """NMGP_POISON=1 fills every fresh device buffer and every scratch hand-out with NaNs: a kernel or library call that
+    reads memory nobody wrote (this caught a beta = 0 dsymm into stale scratch and a zero-weighted contraction over
+    unwritten LDS slots) then fails the parity suite deterministically instead of depending on allocator history."""
+    env = dict(os.environ)
+    env["NMGP_POISON"] = "1"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
+                          "-x", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:]
