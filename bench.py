@@ -282,10 +282,17 @@ def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
 
 
 def cpu_baseline(d, pars, hyper, evals, want_grad):
-    """The CPU oracle on the same subject: 1 warm-up + `evals` timed evaluations (Cholesky formulation, all host
-    cores through the BLAS threads NumPy/SciPy were built with)."""
+    """The CPU oracle on the same subject: 1 warm-up + `evals` timed evaluations (Cholesky formulation); `cores` = the
+    BLAS/LAPACK threads NumPy/SciPy actually use on this host (threadpoolctl), else the affinity mask."""
     from oracle import nmgp_oracle as O     # checker / baseline only
     cores = len(os.sched_getaffinity(0))
+    try:        # the threads the BLAS/LAPACK behind NumPy/SciPy actually runs (the elementwise parts are single-threaded)
+        from threadpoolctl import threadpool_info
+        blas = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            cores = int(max(blas))
+    except Exception:
+        pass
 
     def one():
         return O.nlogpos_obj_SVC(pars, d["Y"], d["x"], **hyper, verbose=True, formulation="cholesky", grad=want_grad)
