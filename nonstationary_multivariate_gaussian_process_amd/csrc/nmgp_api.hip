@@ -120,6 +120,16 @@ bool nmgp_poison() {
     return on;
 }
 
+// leading dimension (doubles) of a column-major factorisation buffer with `rows` rows: a multiple of 16 (64-byte columns);
+// NMGP_LD_EXTRA=<k> adds k doubles (experiments on how the column stride meets the HBM channel interleaving)
+size_t nmgp_ld(size_t rows) {
+    static const size_t extra = [] {
+        const char* e = std::getenv("NMGP_LD_EXTRA");
+        return e ? (size_t)std::atoi(e) : (size_t)0;
+    }();
+    return ((rows + 15) / 16) * 16 + extra;
+}
+
 int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
     DevBuf& b = c->scratch[slot];
     if (b.cap < nelem || !b.p) {
@@ -606,7 +616,7 @@ extern "C" int nmgp_svc_batch_alloc(nmgp_ctx* c, int B) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_batch(c);
     const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc;
-    const size_t ld = ((n + 1 + 15) / 16) * 16;
+    const size_t ld = nmgp_ld(n + 1);
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_pars, (size_t)B * P));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_ell, (size_t)B * N));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_Lv, (size_t)B * N * T));
@@ -706,7 +716,7 @@ static int get_batch_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor**
 static int batch_grad_alloc(nmgp_ctx* c) {
     if (c->b_grad_ready) return 0;
     const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc, B = c->batch;
-    const size_t ld2 = ((2 * n + 2 + 15) / 16) * 16;
+    const size_t ld2 = nmgp_ld(2 * n + 2);
     const size_t NJ = (N + 63) / 64;
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_S2, B * ld2 * n));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_Sinv, B * n * n));
@@ -729,7 +739,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     if (want_grad) NMGP_TRY(batch_grad_alloc(c));
     // value-only: rows = n + 1 (y); with gradient: + pad + n identity rows (-> L^-T), in the larger buffer
     const int xpad = (n + 1) & 1, xoff = n + 1 + xpad;
-    const int ld = want_grad ? (int)((((size_t)2 * n + 2 + 15) / 16) * 16) : (int)((((size_t)n + 1 + 15) / 16) * 16);
+    const int ld = want_grad ? (int)nmgp_ld((size_t)2 * n + 2) : (int)nmgp_ld((size_t)n + 1);
     double* S = want_grad ? c->b_S2 : c->b_S;
     const long long bs = (long long)ld * n;
     const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];

@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
     A += (size_t)blockIdx.y * bstride;
     __shared__ double Lm[64][65];
     __shared__ double Linv[4][16][17];
-    __shared__ double ops[10][4][64];
+    __shared__ v4d ops[10][64];                   // ops[blk][lane] = the four k-slices of the lane's A operand
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // the workgroup handles `reps` groups of 128 rows (the factor preparation is paid once); wave w of group it owns rows
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
         } else {
             v = (kc <= rr) ? Linv[blk - 6][rr][kc] : 0.0;
         }
-        ops[blk][kk][l] = v;
+        reinterpret_cast<double*>(&ops[blk][l])[kk] = v;
     }
     __syncthreads();
     for (int it = 0; it < reps; ++it) {
@@ -1036,19 +1036,19 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
 #pragma unroll
             for (int pp = 0; pp < q; ++pp) {
                 const int blk = (q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp;
+                const v4d av = ops[blk][lane];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const double a = ops[blk][kk][lane];
-                    T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][pp][kk], T[0][q], 0, 0, 0);
-                    T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][pp][kk], T[1][q], 0, 0, 0);
+                    T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[0][pp][kk], T[0][q], 0, 0, 0);
+                    T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[1][pp][kk], T[1][q], 0, 0, 0);
                 }
             }
             v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+            const v4d ai = ops[6 + q][lane];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const double a = ops[6 + q][kk][lane];
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][q][kk], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][q][kk], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[0][q][kk], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[1][q][kk], x1, 0, 0, 0);
             }
             T[0][q] = x0;
             T[1][q] = x1;
