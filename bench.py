@@ -5,7 +5,7 @@ MN = 6144) on MI355X -- BASELINE.json's metric on its configs[2].
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over one batch of synthetic input: ONE evaluation of ``nlogpos_obj_SVC`` for each
-of ``--chains`` (default 64) independent MCMC chains of the rank's subject -- the chains are the reference's
+of ``--chains`` (default 128) independent MCMC chains of the rank's subject -- the chains are the reference's
 embarrassingly-parallel unit (it runs them as separate processes, Nonseparable_model_mpisim.py:305-306); here their
 parameter vectors are stacked [B, P] in HBM and one launch sequence evaluates all of them (nmgp_svc_batch_*), which is
 what amortises the latency-bound panel steps of the Cholesky.  ``value`` counts evaluations: steps x chains x GPUs /
@@ -38,14 +38,14 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (vendor dense figure; SU
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per batched factorisation from the rocprofv3 PMC passes (profiles/, filled in by hand from the committed
 # counter CSVs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 64): 1.800e11}    # (N, M, chains) -> HBM bytes of the k_syrk_lower launches of one
-#                                                         batched factorisation; profiles/r01_v7_batched64_pmc_traffic.json
+TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 128): 3.921e11, (2048, 3, 64): 1.800e11}    # (N, M, chains) -> HBM bytes of the k_syrk_lower launches of one
+#                                                         batched factorisation; profiles/r01_v8_batched128_pmc_traffic.json
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--N", type=int, default=2048)
     ap.add_argument("--M", type=int, default=3)
@@ -54,7 +54,7 @@ def main():
                     help="chain: one N=2048 chain per GPU (headline); subjects: BASELINE config 4, independent "
                          "subjects of size --N sharded round-robin over the GPUs (8 per GPU), one stream each")
     ap.add_argument("--subjects-per-gpu", type=int, default=8)
-    ap.add_argument("--chains", type=int, default=64,
+    ap.add_argument("--chains", type=int, default=128,
                     help="independent MCMC chains of the subject evaluated per step through the batched entry "
                          "(nmgp_svc_batch_*): one launch sequence covers all chains")
     ap.add_argument("--groups", type=int, default=1,
