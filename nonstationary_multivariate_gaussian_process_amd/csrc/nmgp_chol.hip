@@ -1068,7 +1068,84 @@ __global__ __launch_bounds__(256) void k_trsm_64m(const double* __restrict__ L, 
     }
 }
 
+// The common case of k_trsm_64m -- a full 64-column block whose factor carries the inverted diagonal 16x16 blocks
+// (k_potf2_64b) -- with the operands built straight from global memory / L2: no staging of L, no inversion, 20 KB of
+// LDS and <= 128 VGPRs, so FOUR workgroups share a CU instead of two.  The solve is a chain of dependent MFMAs (two
+// interleaved row chunks per wave); only more waves per SIMD put more independent chains on the matrix pipe.
+__global__ __launch_bounds__(256, 4) void k_trsm_64f(const double* __restrict__ L, int ldl, double* __restrict__ A, int lda,
+                                                      int rows, long long bstride) {
+    L += (size_t)blockIdx.y * bstride;
+    A += (size_t)blockIdx.y * bstride;
+    __shared__ v4d ops[10][64];                   // ops[blk][lane] = the four k-slices of the lane's A operand
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int rbase = blockIdx.x * 128 + w * 32 + 2 * l15;       // rows rbase, rbase + 1
+    const bool v0 = rbase < rows, v1 = rbase + 1 < rows;
+    v4d T[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * q + 4 * r + l4;
+            double2 v = make_double2(0.0, 0.0);
+            if (v0) v = *reinterpret_cast<const double2*>(&A[(size_t)col * lda + rbase]);
+            T[0][q][r] = v.x;
+            T[1][q][r] = v1 ? v.y : 0.0;
+        }
+    // entry [row = l & 15][k = 4 kk + (l >> 4)]; blk 0..5 = -L_qp (q = 1: p0; q = 2: p0, p1; q = 3: p0, p1, p2), blk 6 + q = inv(L_qq)
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        const int idx = tid + 256 * e;               // 0 .. 2559
+        const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+        const int rr = l & 15, kc = 4 * kk + (l >> 4);
+        double v;
+        if (blk < 6) {
+            const int q = blk == 0 ? 1 : (blk < 3 ? 2 : 3);
+            const int pp = blk == 0 ? 0 : (blk < 3 ? blk - 1 : blk - 3);
+            v = -L[(size_t)(16 * pp + kc) * ldl + 16 * q + rr];
+        } else {
+            const int q = blk - 6;                   // inv(L_qq)[rr][kc] (kc < rr) sits at row 16 q + kc, column 16 q + rr
+            if (kc < rr) v = L[(size_t)(16 * q + rr) * ldl + 16 * q + kc];
+            else if (kc == rr) v = 1.0 / L[(size_t)(16 * q + rr) * ldl + 16 * q + rr];
+            else v = 0.0;
+        }
+        reinterpret_cast<double*>(&ops[blk][l])[kk] = v;
+    }
+    __syncthreads();
+    if (blockIdx.x * 128 + w * 32 >= rows) return;               // wave-uniform (the MFMAs need every lane)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int pp = 0; pp < q; ++pp) {
+            const v4d av = ops[(q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp][lane];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[0][pp][kk], T[0][q], 0, 0, 0);
+                T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[1][pp][kk], T[1][q], 0, 0, 0);
+            }
+        }
+        const v4d ai = ops[6 + q][lane];
+        v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[0][q][kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[1][q][kk], x1, 0, 0, 0);
+        }
+        T[0][q] = x0;
+        T[1][q] = x1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * q + 4 * r + l4;
+            if (v1) *reinterpret_cast<double2*>(&A[(size_t)col * lda + rbase]) = make_double2(T[0][q][r], T[1][q][r]);
+            else if (v0) A[(size_t)col * lda + rbase] = T[0][q][r];
+        }
+}
+
 static int g_trsm_valu = -1;     // NMGP_TRSM=valu selects the substitution kernel (k_trsm_64)
+static int g_trsm_slow = 0;      // NMGP_TRSM=staged keeps full blocks on the general matrix-core kernel (k_trsm_64m)
 static int g_potf2_exports_inv();  // 1 when the block factorisation in use leaves inv(L_qq) in the diagonal blocks
 
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
@@ -1077,11 +1154,13 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
     if (g_trsm_valu < 0) {
         const char* e = std::getenv("NMGP_TRSM");
         g_trsm_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+        g_trsm_slow = (e && std::strcmp(e, "staged") == 0) ? 1 : 0;
     }
-    if (g_trsm_valu || g_precise)
+    if (g_trsm_valu || g_precise) {
         hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
-    else
-    {
+    } else if (nb == 64 && g_potf2_exports_inv() && !g_trsm_slow) {
+        hipLaunchKernelGGL(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
+    } else {
         // groups of 128 rows per workgroup: more of them amortise the factor preparation once the launch would fill the
         // chip (512 resident workgroups) several times over anyway
         const long long wgs = (long long)cdiv_c(rows, 128) * batch;
