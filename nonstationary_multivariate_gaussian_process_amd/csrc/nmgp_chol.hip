@@ -1113,26 +1113,27 @@ __global__ __launch_bounds__(256, 4) void k_trsm_64f(const double* __restrict__ 
     }
     __syncthreads();
     if (blockIdx.x * 128 + w * 32 >= rows) return;               // wave-uniform (the MFMAs need every lane)
+    // right-looking order: once X_p is solved, its updates of the blocks q > p are independent of each other (up to six
+    // accumulator chains in flight instead of two)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int pp = 0; pp < q; ++pp) {
-            const v4d av = ops[(q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp][lane];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[0][pp][kk], T[0][q], 0, 0, 0);
-                T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[1][pp][kk], T[1][q], 0, 0, 0);
-            }
-        }
-        const v4d ai = ops[6 + q][lane];
+    for (int pp = 0; pp < 4; ++pp) {
+        const v4d ai = ops[6 + pp][lane];
         v4d x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[0][q][kk], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[1][q][kk], x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[0][pp][kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[1][pp][kk], x1, 0, 0, 0);
         }
-        T[0][q] = x0;
-        T[1][q] = x1;
+        T[0][pp] = x0;
+        T[1][pp] = x1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int q = pp + 1; q < 4; ++q) {
+                const double a = reinterpret_cast<const double*>(&ops[(q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp][lane])[kk];
+                T[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[0][pp][kk], T[0][q], 0, 0, 0);
+                T[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[1][pp][kk], T[1][q], 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
