@@ -38,8 +38,8 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix (vendor dense figure; SU
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per batched factorisation from the rocprofv3 PMC passes (profiles/, filled in by hand from the committed
 # counter CSVs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 128): 3.921e11, (2048, 3, 64): 1.800e11}    # (N, M, chains) -> HBM bytes of the k_syrk_lower launches of one
-#                                                         batched factorisation; profiles/r01_v8_batched128_pmc_traffic.json
+TRAFFIC_BYTES_PER_LAUNCH = {(2048, 3, 128): 3.907e11, (2048, 3, 64): 1.800e11}    # (N, M, chains) -> HBM bytes of the k_syrk_lower launches of one
+#                                                         batched factorisation; profiles/r01_v9_batched128_pmc_traffic.json
 
 
 def main():
