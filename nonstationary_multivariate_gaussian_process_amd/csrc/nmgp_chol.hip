@@ -711,8 +711,66 @@ __device__ __forceinline__ void potf2b_steps4(double (&a)[4], double (&e)[4], do
     potf2b_step<KC, 3>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
 }
 
+// The same pivot step with the cross-lane traffic on the DPP / LDS-crossbar paths instead of an LDS write + read round
+// trip: thread (r, g) = (lane >> 2, lane & 3), so that a row's four column classes sit in one quad.  Column c lives in
+// register slot KC of the lanes with g = GC: the pivot comes by v_readlane (compile-time lane), the row's own entry by a
+// DPP quad broadcast, the entries S[4 kk + g][c] and the row E[c][.] by ds_bpermute (no LDS memory involved).
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bperm_f64(double v, int srclane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(srclane * 4, lo);
+    hi = __builtin_amdgcn_ds_bpermute(srclane * 4, hi);
+    return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ double quad_bcast_f64(double v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int KC, int GC>
+__device__ __forceinline__ void potf2x_step(double (&a)[4], double (&e)[4], double* pivs, double* Sqq, int q,
+                                            int* __restrict__ info, int goff, int r, int g, int lane) {
+    constexpr int c = 4 * KC + GC;
+    const double piv = readlane_f64(a[KC], 4 * c + GC);
+    const double mine = quad_bcast_f64<GC>(a[KC]);
+    double t[4], er[4];
+#pragma unroll
+    for (int kk = KC; kk < 4; ++kk) t[kk] = bperm_f64(a[KC], 16 * kk + 4 * g + GC);     // S[4 kk + g][c]
+#pragma unroll
+    for (int kk = 0; kk <= KC; ++kk) er[kk] = bperm_f64(e[kk], 4 * c + g);              // E[c][4 kk + g]
+    const double pinv = fast_recip(piv);
+    const double f = (r > c) ? mine * pinv : 0.0;          // rows up to the pivot row are final
+#pragma unroll
+    for (int kk = KC; kk < 4; ++kk) a[kk] = fma(-f, t[kk], a[kk]);
+#pragma unroll
+    for (int kk = 0; kk <= KC; ++kk) e[kk] = fma(-f, er[kk], e[kk]);
+    if (g == GC) Sqq[c * PB_LD + r] = mine;                // the finished (unscaled) column goes back to the block
+    if (lane == 0) {
+        pivs[16 * q + c] = piv;
+        if (!(piv > 0.0)) atomicCAS(info, 0, goff + 16 * q + c + 1);
+    }
+}
+
+template <int KC>
+__device__ __forceinline__ void potf2x_steps4(double (&a)[4], double (&e)[4], double* pivs, double* Sqq, int q,
+                                              int* __restrict__ info, int goff, int r, int g, int lane) {
+    potf2x_step<KC, 0>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2x_step<KC, 1>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2x_step<KC, 2>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+    potf2x_step<KC, 3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+}
+
 __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
-                                                    int goff, long long bstride, int istride) {
+                                                    int goff, long long bstride, int istride, int xbar) {
     A += (size_t)blockIdx.x * bstride;
     info += (size_t)blockIdx.x * istride;
     __shared__ double S[64 * PB_LD];            // S[col * PB_LD + row]
@@ -733,7 +791,30 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
     __syncthreads();
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        if (w == 0) {
+        if (w == 0 && xbar) {
+            // (A), register / crossbar flavour: thread (r, g) = (lane >> 2, lane & 3)
+            const int r = lane >> 2, g = lane & 3;
+            double a[4], e[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cc = 4 * kk + g;
+                a[kk] = (cc <= r) ? S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
+                e[kk] = (cc == r) ? 1.0 : 0.0;
+            }
+            double* Sqq = &S[(16 * q) * PB_LD + 16 * q];
+            potf2x_steps4<0>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<1>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<2>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+            __builtin_amdgcn_wave_barrier();
+            const double sr = rsqrt(pivs[16 * q + r]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cc = 4 * kk + g;
+                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(pivs[16 * q + cc]);
+                Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
+            }
+        } else if (w == 0) {
             // (A) thread (r, g) = (lane & 15, lane >> 4) keeps S_qq[r][4 kk + g] and E[r][4 kk + g], kk = 0..3
             const int r = l15, g = l4;
             double a[4], e[4];
@@ -817,6 +898,7 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
 }
 
 static int g_potf2_valu = -1;     // NMGP_POTF2=valu selects the unblocked kernel (k_potf2_64)
+static int g_potf2_xbar = 1;      // NMGP_POTF2=lds: pivot steps of k_potf2_64b through an LDS column instead of DPP / bpermute
 // set by potrf_lower(precise = 1): substitution-based panel kernels (no inverted 16x16 blocks) for the ill-conditioned,
 // cached prior covariances (RBF + 1e-6 I, condition number up to 1e11), where the inverse-based solves cost parity digits
 static thread_local int g_precise = 0;
@@ -827,17 +909,19 @@ void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, in
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
     }
     if (g_potf2_valu || g_precise)
         hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
     else
-        hipLaunchKernelGGL(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
+        hipLaunchKernelGGL(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride, g_potf2_xbar);
 }
 
 static int g_potf2_exports_inv() {
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
+        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
     }
     return (g_potf2_valu || g_precise || g_fuse.on) ? 0 : 1;
 }

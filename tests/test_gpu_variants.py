@@ -34,7 +34,7 @@ print(json.dumps({"out": list(map(float, out)), "grad": list(map(float, grad)), 
                   "status": status.tolist()}))
 """
 
-VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
+VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "valu"}, {"NMGP_POTF2": "lds"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
             {"NMGP_SYRK_YROW": "0"}, {"NMGP_SYRK_HALF": "0"}, {"NMGP_SYRK_SWIZZLE": "0"}, {"NMGP_SYRK_WAVES": "4"},
             {"NMGP_FUSE_POTF2": "1"}, {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"},
             {"NMGP_POISON": "1"}]
