@@ -1326,7 +1326,11 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
 
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
-    if (batch >= 4)
+    static const int rec_min_batch = [] {       // NMGP_CHOL_REC_MIN_BATCH: smallest batch that takes the recursive panels
+        const char* e = std::getenv("NMGP_CHOL_REC_MIN_BATCH");
+        return e ? std::atoi(e) : 4;
+    }();
+    if (batch >= rec_min_batch)
         factor_panel_rec(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
