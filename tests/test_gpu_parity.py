@@ -399,6 +399,29 @@ def test_batched_chains_match_single_evaluations(ctx):
     assert np.all(np.isnan(out[1])) and relerr(out[0], g["out"]) < VAL_TOL and np.array_equal(out[0], out[2])
 
 
+def test_large_batches_at_full_size_match_the_golden_vector_and_single_evaluations(ctx):
+    """The benchmark's configuration in small: 16 chains of the N = 2048, D = 3 subject per launch sequence take the widest
+    outer panels (2048) and the recursive panel factorisation; 4 chains take 1024.  Chain 0 carries the golden parameters
+    (reference output committed under tests/golden), the others are checked against single-chain evaluations, which
+    factor with 512-wide panels and right-looking 64-wide steps."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    g = golden("svc_sim_N2048_M3_base")
+    ctx.set_data(g["x"], g["Y"])
+    for B in (16, 4):
+        ctx.svc_batch_alloc(B)
+        pars = np.stack([sim.perturb(g["pars"], 0.01 * k, 0.2 * k) for k in range(B)])
+        pars[0] = g["pars"]
+        ctx.svc_batch_set_pars(pars)
+        ctx.svc_batch_eval(g["hyper"], True)
+        out, status = ctx.svc_batch_fetch()
+        assert np.all(status == 0)
+        assert relerr(out[0], g["out"]) < VAL_TOL and relerr(out[0][1], g["out"][1]) < LIK_TOL
+        for k in (1, B // 2, B - 1):
+            single = ctx.logpos_svc(pars[k], g["hyper"], prior=True, want_grad=False)[0]
+            assert relerr(out[k][1], single[1]) < 1e-11 and relerr(out[k], single) < 1e-9, (B, k, out[k], single)
+    ctx.svc_batch_alloc(1)      # release the batch buffers (16 x 0.3 GB)
+
+
 def test_separable_cholesky_and_eigen_formulations_agree():
     """The default separable/stationary path factors M blocks wB[p] K + sigma2 I with the batched Cholesky; the
     reference's eigen-trick formulation (distributions.py:26-52) stays selectable and must give the same numbers."""
