@@ -419,7 +419,15 @@ def test_large_batches_at_full_size_match_the_golden_vector_and_single_evaluatio
         for k in (1, B // 2, B - 1):
             single = ctx.logpos_svc(pars[k], g["hyper"], prior=True, want_grad=False)[0]
             assert relerr(out[k][1], single[1]) < 1e-11 and relerr(out[k], single) < 1e-9, (B, k, out[k], single)
-    ctx.svc_batch_alloc(1)      # release the batch buffers (16 x 0.3 GB)
+    # gradients of the 4-chain batch (L^-T rows ride along, 1024-wide panels) against the golden gradient / a single evaluation
+    ctx.svc_batch_eval(g["hyper"], True, want_grad=True)
+    outg, statusg = ctx.svc_batch_fetch()
+    grads = ctx.svc_batch_fetch_grad()
+    assert np.all(statusg == 0) and relerr(outg, out) < 1e-9
+    assert vec_relerr(grads[0], g["grad"]) < GRAD_TOL
+    gsingle = ctx.logpos_svc(pars[3], g["hyper"], prior=True, want_grad=True)[1]
+    assert vec_relerr(grads[3], gsingle) < 1e-8
+    ctx.svc_batch_alloc(1)      # release the batch buffers
 
 
 def test_separable_cholesky_and_eigen_formulations_agree():
