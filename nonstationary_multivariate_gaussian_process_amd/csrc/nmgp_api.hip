@@ -208,6 +208,7 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     }
     HIP_TRY(c, hipSetDevice(device));
     if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);
+    if (const char* e = std::getenv("NMGP_PRIOR_SOLVE")) c->prior_rocblas = std::strcmp(e, "rocblas") == 0;
     if (const char* e = std::getenv("NMGP_SEP")) c->sep_algo = (std::strcmp(e, "eig") == 0) ? 0 : 1;
     {
         // The main stream carries the latency-bound panel steps of the factorisation, stream2 the far trailing updates
@@ -472,6 +473,8 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         StageScope sp(c, NMGP_STAGE_PRIOR);
         const double one = 1.0;
         svc_prior_rhs(s, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
+        // (a single subject's 1 + T columns stay with the library: k_prior_trsv needs tens of workgroups to win, its
+        // 7 workgroups took 0.69 ms against 0.26 ms at N = 2048)
         if (pl == pL) {
             BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                       rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R, N));
@@ -797,7 +800,11 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
             if (pass == 1)
                 HIP_TRY(c, hipMemcpyAsync(c->b_R2, c->b_R, (size_t)N * B * (1 + T) * sizeof(double),
                                           hipMemcpyDeviceToDevice, s));
-            if (multi) {
+            if (multi && N <= 3500 && B * (1 + T) >= 32 && !c->prior_rocblas) {
+                // per-subject factors, a handful of right-hand sides each: one streaming pass per column (k_prior_trsv)
+                prior_trsv(s, pass == 1, pl->L, pl->ld, (long long)pl->ld * N, pL->L, pL->ld, (long long)pL->ld * N, R, N, 1 + T,
+                           (int)B);
+            } else if (multi) {
                 // per-subject factors: strided-batched solves (columns of chain b start at b (1+T) N)
                 const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;
                 const rocblas_stride sB = (rocblas_stride)(1 + T) * N;

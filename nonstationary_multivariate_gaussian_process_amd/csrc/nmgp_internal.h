@@ -125,6 +125,7 @@ struct nmgp_ctx {
     int last_kind = 0;          // 1 svc
 
     int chol_algo = 1;          // 0 = rocSOLVER dpotrf + rocBLAS dtrsv, 1 = custom blocked factorisation (nmgp_chol.hip)
+    bool prior_rocblas = false;               // NMGP_PRIOR_SOLVE=rocblas: library batched trsm for per-subject prior factors
     int chol_nb1 = 0;           // outer panel width of the custom factorisation; 0 = auto (1024 for batches of large matrices, else 512)
     int profiling = 0;                        // 0 off, 1 stage timers, 2 + one event pair per k_syrk_lower launch
     StageTimer timers[NMGP_STAGE_COUNT];
@@ -196,6 +197,9 @@ void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* 
 void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
                       double* out_quad, int batch = 1, long long bstride = 0, int ostride = 0);
 void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out);
+// op(L) x = r for the columns r of R ([N] each, nrhs per batch element); column 0 uses L0, the others L1; N <= 3500 (LDS)
+void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
+                double* R, int N, int nrhs, int batch);
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out);
 void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch = 1);
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);

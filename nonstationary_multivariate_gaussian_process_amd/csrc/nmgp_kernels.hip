@@ -692,4 +692,97 @@ void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int
     hipLaunchKernelGGL(k_half_logdet, dim3(batch), dim3(1024), 0, s, L, ld, n, out);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Per-subject prior solves  op(L) x = r  for the few right-hand sides of the GP priors (1 + T columns per subject: the
+// centred tilde_l and the T columns of uL_vecs), one workgroup per (column, subject).  With every subject bringing its
+// own N x N factor the library's batched trsm (inverted diagonal blocks + many small GEMMs) took 1 ms of a 5 ms step for
+// 8 subjects of N = 1024; a right-hand side is a streaming pass over its factor: 64-wide substitution steps by one wave
+// on a diagonal block staged in LDS, the rest of the column block applied as a GEMV by the whole workgroup.
+// TRANS = false: L x = r (forward), TRANS = true: L^T x = r (backward; the gradient of the prior terms).
+// Column j of subject b: r = R + (b * nrhs + j) * N; its factor is L0 for j = 0 and L1 for j >= 1 (strides s0 / s1).
+// ---------------------------------------------------------------------------------------------
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_prior_trsv(const double* __restrict__ L0, int ld0, long long s0,
+                                                     const double* __restrict__ L1, int ld1, long long s1,
+                                                     double* __restrict__ R, int N, int nrhs) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const double* L = (j == 0 ? L0 + (size_t)b * s0 : L1 + (size_t)b * s1);
+    const int ld = (j == 0 ? ld0 : ld1);
+    double* r = R + ((size_t)b * nrhs + j) * N;
+    extern __shared__ double sh[];
+    double* rv = sh;                        // [N]   the right-hand side / solution
+    double* Ld = sh + N;                    // [64][65] diagonal block, Ld[c * 65 + r]
+    double* xs = Ld + 64 * 65;              // [64]  the block's solution
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < N; i += 256) rv[i] = r[i];
+    const int nblk = (N + 63) / 64;
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int kb = (TRANS ? nblk - 1 - bb : bb) * 64;
+        const int nbk = N - kb < 64 ? N - kb : 64;
+        __syncthreads();                    // rv up to date, Ld / xs free
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int rr = e & 63, cc = e >> 6;
+            Ld[cc * 65 + rr] = (rr < nbk && cc <= rr) ? L[(size_t)(kb + cc) * ld + kb + rr] : (rr == cc ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (w == 0) {
+            double v = lane < nbk ? rv[kb + lane] : 0.0;
+            const double d = Ld[lane * 65 + lane];
+            if (!TRANS) {
+                for (int k = 0; k < nbk; ++k) {
+                    const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k),
+                                                       __builtin_amdgcn_readlane(__double2loint(v), k)) /
+                                      __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), k),
+                                                       __builtin_amdgcn_readlane(__double2loint(d), k));
+                    const double lik = Ld[k * 65 + lane];              // L[kb + lane][kb + k]
+                    v = (lane == k) ? xk : (lane > k ? v - lik * xk : v);
+                }
+            } else {
+                for (int k = nbk - 1; k >= 0; --k) {
+                    const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k),
+                                                       __builtin_amdgcn_readlane(__double2loint(v), k)) /
+                                      __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), k),
+                                                       __builtin_amdgcn_readlane(__double2loint(d), k));
+                    const double lki = Ld[lane * 65 + k];              // L[kb + k][kb + lane]
+                    v = (lane == k) ? xk : (lane < k ? v - lki * xk : v);
+                }
+            }
+            xs[lane] = v;
+            if (lane < nbk) rv[kb + lane] = v;
+        }
+        __syncthreads();
+        if (!TRANS) {
+            // rows below the block: r[i] -= sum_k L[i][kb + k] x[k]   (coalesced along i)
+            for (int i = kb + 64 + tid; i < N; i += 256) {
+                double acc = rv[i];
+                const double* Lc = L + (size_t)kb * ld + i;
+#pragma unroll 8
+                for (int k = 0; k < 64; ++k) acc = fma(-Lc[(size_t)k * ld], xs[k], acc);
+                rv[i] = acc;
+            }
+        } else {
+            // columns left of the block: r[i] -= sum_k L[kb + k][i] x[k]   (64 contiguous doubles of column i)
+            for (int i = tid; i < kb; i += 256) {
+                double acc = rv[i];
+                const double* Lc = L + (size_t)i * ld + kb;
+#pragma unroll 8
+                for (int k = 0; k < 64; ++k) acc = fma(-(k < nbk ? Lc[k] : 0.0), xs[k], acc);
+                rv[i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) r[i] = rv[i];
+}
+
+void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
+                double* R, int N, int nrhs, int batch) {
+    const size_t lds = ((size_t)N + 64 * 65 + 64) * sizeof(double);
+    if (trans)
+        hipLaunchKernelGGL(k_prior_trsv<true>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+    else
+        hipLaunchKernelGGL(k_prior_trsv<false>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+}
+
 }  // namespace nmgpk
