@@ -246,6 +246,7 @@ def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
         ctx.svc_batch_eval(hv, True, want_grad)
         return ctx.svc_batch_fetch()
 
+    ctx.profile_enable(True)        # stage timers (their events are created during the warm-up)
     for _ in range(a.warmup):
         outs, status = step()
 
@@ -255,12 +256,19 @@ def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
         torch.cuda.synchronize()
         ctx.sync()
 
+    ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         outs, status = step()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, world, torch, dist)
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1] > 0}
+    n = N * M
+    chol_s = stage_ms.get("chol", 0.0) * 1e-3
+    fact_tf = (len(mine) * (2.0 if want_grad else 1.0) * n ** 3 / 3.0) / chol_s / 1e12 if chol_s > 0 else 0.0
     rows = np.array([[s_id, float(st == 0), a.steps] + [float(v) for v in o[:5]]
                      for s_id, o, st in zip(mine, outs, status)])
     stats, table = chains.reduce_rows(rows, n_subj, world, device="cuda")
@@ -274,7 +282,12 @@ def bench_subjects(a, rank, world, local_rank, torch, dist, _lib, chains, sim):
             "config": {"workload": "%d independent subjects (%d per GPU, one multi-subject batch per GPU), "
                                    "nlogpos_obj_SVC %s, D=%d, N=%d" % (n_subj, a.subjects_per_gpu,
                                                                        "value+gradient" if want_grad else "value", M, N),
-                       "subjects_ok": int(stats[0]), "sum_neglog": float(stats[3])}}), flush=True)
+                       "subjects_ok": int(stats[0]), "sum_neglog": float(stats[3]), "stage_ms": stage_ms},
+            "roofline": {"kernel": "blocked FP64 Cholesky stage of rank 0's multi-subject batch (k_syrk_lower + panel kernels%s): "
+                                   "subjects * n^3/3 flop%s over the HIP-event stage time" % (
+                                       ", with the L^-T rows" if want_grad else "", " x 2" if want_grad else ""),
+                         "bound": "mfma", "achieved": fact_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fact_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None}}), flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()
