@@ -51,3 +51,9 @@ def inverse_gamma_logpdf(x, alpha=1., beta=1.):
 def gamma_logpdf(x, alpha=1., beta=1.):
     """reference distributions.py:136-137."""
     return (alpha - 1) * torch.log(x) - beta * x + alpha * np.log(beta) - lgamma(alpha)
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

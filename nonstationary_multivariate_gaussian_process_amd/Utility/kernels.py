@@ -26,3 +26,9 @@ def Nonstationary_RBF_cov(X1, sigma1=None, ell1=None, X2=None, sigma2=None, ell2
         # the reference would fail on None.view(); keep the failure loud
         raise TypeError("Nonstationary_RBF_cov: sigma2 and ell2 are required when X2 is given")
     return to_t(ctx().nonstat_rbf_cov(to_np(X1), to_np(sigma1), to_np(ell1), to_np(X2), to_np(sigma2), to_np(ell2)))
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

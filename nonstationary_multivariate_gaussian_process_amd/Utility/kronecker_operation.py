@@ -34,3 +34,9 @@ def kron_mv(B, K, y):
     """(B kron K) y = vec(K Y B^T) without forming the product; reference kronecker_operation.py:72-85."""
     no_grad_inputs("kron_mv", B, K, y)
     return to_t(ctx().kron_mv(to_np(B), to_np(K), to_np(y)))
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

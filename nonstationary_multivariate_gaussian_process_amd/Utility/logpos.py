@@ -226,3 +226,9 @@ def deviance(tilde_l, tilde_sigma, L_vec, tilde_sigma2_err, Y, x):
     loglik = distributions.multivariate_normal_logpdf0(y, torch.zeros_like(y), B_f, K_x,
                                                        torch.exp(_as_tensor(tilde_sigma2_err).detach()))
     return -2 * loglik
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

@@ -104,3 +104,9 @@ def test_predmap_S(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, test_x,
     """Stationary model: (mean [S, M], std [S, M]); reference prediction.py:1601-1638."""
     mean, var = _sta(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, test_x)
     return to_t(mean), to_t(np.sqrt(var))
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

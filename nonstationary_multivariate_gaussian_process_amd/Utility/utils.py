@@ -91,3 +91,9 @@ def lowtriangle2vec(L, N=None):
         return L[idx[0], idx[1]]
     idx = np.tril_indices(N)
     return L[idx[0], idx[1]]
+
+
+def __getattr__(name):
+    """Names outside the mirrored path come from the user's reference checkout (Utility/_overlay.py)."""
+    from . import _overlay
+    return _overlay.module_getattr(__name__, name)

@@ -12,11 +12,23 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_utility_alias():
+def install_utility_alias(reference_utility_dir=None):
     """Register this package's ``Utility`` mirror under the top-level name the reference's scripts import
-    (``sys.path.append(".."); from Utility import logpos``, Nonseparable_model.py:27-36)."""
+    (``sys.path.append(".."); from Utility import logpos``, Nonseparable_model.py:27-36).
+
+    The mirror OVERLAYS the user's own reference checkout instead of replacing it: the hot-path modules and functions
+    (logpos objectives, kernels, kronecker_operation, distributions, the tril helpers of utils, deterministic prediction)
+    are the MI355X ones; every other submodule or name the scripts use (``visualization``, ``posterior_analysis``,
+    ``model_validation``, ``preprocess_realdata``, ``empirical_estimation``, ``utils.data_split/MSE/RMSE/LPD``,
+    ``prediction.vec2pars/vec2list/*_sampling``) is resolved from the reference's ``Utility`` directory --
+    ``reference_utility_dir`` if given, else ``$NMGP_REFERENCE_UTILITY``, else the first ``Utility`` directory found on
+    ``sys.path`` when such a name is first needed (the scripts append ".." before importing).  Nothing of the reference
+    is copied or shipped."""
     from . import Utility
+    from .Utility import _overlay
     sys.modules["Utility"] = Utility
     for name in ("settings", "utils", "kernels", "kronecker_operation", "distributions", "logpos", "prediction"):
         sys.modules["Utility." + name] = getattr(Utility, name)
+    if reference_utility_dir is not None:
+        _overlay.attach(reference_utility_dir)
     return Utility

@@ -216,6 +216,15 @@ def multivariate_normal_logpdf0(y, mu, B, K, sigma2):
     return float(-0.5 * np.log(t + sigma2).sum() - 0.5 * np.sum(a * a / (t + sigma2)))
 
 
+def multivariate_normal_logpdf1(y, mu, B, K, sigma2, jitter_B, jitter_K):
+    """The robust variant, distributions.py:55-96: logpdf0 after `precision * u` has been added to the diagonals of B
+    (:66) and K (:69).  u are the reference's ``torch.rand`` draws (B first, then K); the oracle takes them as
+    arguments (jitter_B [M], jitter_K [N], uniform in [0, 1)) so that a seeded reference call can be reproduced."""
+    Bj = np.asarray(B, dtype=np.float64) + np.diag(np.asarray(jitter_B, dtype=np.float64) * PRECISION)
+    Kj = np.asarray(K, dtype=np.float64) + np.diag(np.asarray(jitter_K, dtype=np.float64) * PRECISION)
+    return multivariate_normal_logpdf0(y, mu, Bj, Kj, sigma2)
+
+
 def multivariate_normal_logpdf2(y, mu, B, K, sigma2):
     """Dense evaluation of the same density; distributions.py:99-113."""
     S = kronecker_product(B, K) + sigma2 * np.eye(B.shape[0] * K.shape[0])

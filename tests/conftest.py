@@ -45,3 +45,14 @@ def vec_relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def prior_term_err(a, b, N):
+    """Error measure for the verbose GP-prior components (lp_l, lp_uL) at sizes where they are a small difference of
+    large terms: each is -N/2 log 2pi - 1/2 log det - 1/2 q with 1/2 |log det| ~ N/2 |log jitter| (most eigenvalues of
+    RBF + 1e-6 I sit at the jitter floor), so the error is taken relative to max(|component|, that scale).  The log
+    posterior itself (their sum with the likelihood) is always checked at the plain 1e-6 relative north-star bar."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(b), 0.5 * N * abs(np.log(1e-6)))
+    return float(np.max(np.abs(a - b) / scale))

@@ -270,6 +270,78 @@ def gen_map(only):
          pars_end=Pend, lr=0.2, steps=steps)
 
 
+def gen_cfg4(only):
+    """BASELINE config 4 at its real per-GPU shape: 8 subjects (seeds 0..7, sim.py:361-363), N = 1024, D = 3, the mpisim
+    hyper-parameters (Nonseparable_model_mpisim.py:311-312), parameters = the smooth perturbation bench.py's subjects workload
+    evaluates at.  One file: xs [8, N], Ys [8, N, M], pars [8, P], reference outs [8, 5] and autograd grads [8, P]."""
+    name = "cfg4_subjects_N1024_M3"
+    if only and not name.startswith(only):
+        return
+    N, M, S = 1024, 3, 8
+    xs, Ys, ps, outs, grads, secs, pts, outs_t, grads_t = [], [], [], [], [], [], [], [], []
+    for s in range(S):
+        d = sim.simulate_nonseparable(N, M, seed=s)
+        pars = sim.perturb(d["pars_true"], 0.05, 0.7)
+        vals, g, dt = run_obj(logpos.nlogpos_obj_SVC, pars, d["Y"], d["x"], sim.HYPER_SVC_MPISIM, True)
+        # ... and at the generating parameters (smooth curves: the GP-prior terms do not swamp the likelihood there)
+        vt, gt, dt2 = run_obj(logpos.nlogpos_obj_SVC, d["pars_true"], d["Y"], d["x"], sim.HYPER_SVC_MPISIM, True)
+        xs.append(d["x"]); Ys.append(d["Y"]); ps.append(pars); outs.append(vals); grads.append(g); secs.append(dt)
+        pts.append(d["pars_true"]); outs_t.append(vt); grads_t.append(gt)
+        print("  subject %d: NegLog %.10g (%.1f s), at truth %.10g" % (s, vals[0], dt, vt[0]), flush=True)
+    save(name, kind="cfg4", xs=np.stack(xs), Ys=np.stack(Ys), pars=np.stack(ps), out=np.stack(outs), grad=np.stack(grads),
+         pars_true=np.stack(pts), out_true=np.stack(outs_t), grad_true=np.stack(grads_t),
+         hyper=hyper_vec(sim.HYPER_SVC_MPISIM, SVC_KEYS), seeds=np.arange(S), ref_seconds=np.array(secs))
+
+
+def gen_sep_big(only):
+    """BASELINE config 5 at its real shape: separable model, N = 4096, D = 5 (logpos.py:216-296)."""
+    name = "sep_sim_N4096_M5"
+    if only and not name.startswith(only):
+        return
+    d = sim.simulate_separable(4096, 5, 8)
+    sep_case(name, d["x"], d["Y"], sim.perturb(d["pars_true"], 0.05, 0.4), sim.HYPER_SEP)
+
+
+def gen_logpdf1(only):
+    """multivariate_normal_logpdf1 (distributions.py:55-96): the jitter is drawn with torch.rand (B first, then K), so a
+    torch.manual_seed right before the call makes the reference's value reproducible."""
+    name = "prims_logpdf1"
+    if only and not name.startswith(only):
+        return
+    rng = np.random.default_rng(21)
+    out = {}
+    cases = []
+    # (a) generic SPD B, K; (b) K with exactly repeated eigenvalues (the situation the jitter exists for: RBF rows that
+    # coincide); (c) a smooth Gibbs K at the 1e-6 jitter floor with a rank-deficient B
+    B = rng.standard_normal((3, 3)); B = B @ B.T
+    K = rng.standard_normal((6, 6)); K = K @ K.T
+    cases.append((B, K, rng.standard_normal(18), 0.37, 101))
+    Q, _ = np.linalg.qr(rng.standard_normal((12, 12)))
+    K2 = (Q * np.array([2.0] * 4 + [0.5] * 4 + [1e-3] * 4)) @ Q.T
+    K2 = 0.5 * (K2 + K2.T)
+    B2 = np.array([[1.0, 0.3], [0.3, 1.0]])
+    cases.append((B2, K2, rng.standard_normal(24), 0.05, 202))
+    x = np.linspace(0.05, 0.95, 40)
+    K3 = kernels.Nonstationary_RBF_cov(t(x).view(-1, 1), sigma1=t(np.exp(0.3 * np.sin(3 * x))),
+                                       ell1=t(np.exp(3 * (x - 1) ** 3 - 1))).numpy()
+    l = np.array([[1.0, 0, 0], [0.5, 1e-4, 0], [0.2, 0.1, 1e-4]])
+    cases.append((l @ l.T, K3, rng.standard_normal(120), 1e-2, 303))
+    for k, (Bk, Kk, yk, s2, seed) in enumerate(cases):
+        torch.manual_seed(seed)
+        v1 = float(distributions.multivariate_normal_logpdf1(t(yk), torch.zeros(len(yk), dtype=T64), t(Bk), t(Kk),
+                                                             torch.tensor(s2, dtype=T64)))
+        v0 = float(distributions.multivariate_normal_logpdf0(t(yk), torch.zeros(len(yk), dtype=T64), t(Bk), t(Kk),
+                                                             torch.tensor(s2, dtype=T64)))
+        torch.manual_seed(seed)
+        jB = torch.rand(Bk.shape[0]).type(torch.DoubleTensor).numpy()
+        jK = torch.rand(Kk.shape[0]).type(torch.DoubleTensor).numpy()
+        out.update({"B%d" % k: Bk, "K%d" % k: Kk, "y%d" % k: yk, "sig2_%d" % k: s2, "seed%d" % k: seed,
+                    "logpdf1_%d" % k: v1, "logpdf0_%d" % k: v0, "jitterB%d" % k: jB, "jitterK%d" % k: jK})
+        print("  logpdf1 case %d: %.12g (logpdf0 %.12g)" % (k, v1, v0), flush=True)
+    out["ncases"] = len(cases)
+    save(name, **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -281,3 +353,6 @@ if __name__ == "__main__":
     gen_sta(a.only)
     gen_pred(a.only)
     gen_map(a.only)
+    gen_cfg4(a.only)
+    gen_sep_big(a.only)
+    gen_logpdf1(a.only)

@@ -3,7 +3,8 @@
 import numpy as np
 import pytest
 
-from conftest import (SEP_KEYS, STA_KEYS, SVC_KEYS, golden, golden_names, hyper_dict, relerr, vec_relerr)
+from conftest import (SEP_KEYS, STA_KEYS, SVC_KEYS, golden, golden_names, hyper_dict, prior_term_err, relerr,
+                      vec_relerr)
 from oracle import nmgp_oracle as O
 
 VAL_TOL = 1e-6      # north-star tolerance on the log-posterior (relative); the GP-prior terms are ill-conditioned
@@ -71,6 +72,40 @@ def test_svc(name):
         if want_grad:
             assert vec_relerr(grad, g["grad"]) < GRAD_TOL
             assert abs(np.linalg.norm(grad) / float(g["grad_norm"]) - 1) < GRAD_TOL
+
+
+def test_logpdf1_seeded_jitter():
+    """a10: the reference's jittered fallback density on seeded draws (distributions.py:55-96); the stored draws also pin
+    that torch's RNG stream still produces what the fixture was generated with."""
+    import torch
+    g = golden("prims_logpdf1")
+    for k in range(int(g["ncases"])):
+        torch.manual_seed(int(g["seed%d" % k]))
+        jB = torch.rand(g["B%d" % k].shape[0]).type(torch.DoubleTensor).numpy()
+        jK = torch.rand(g["K%d" % k].shape[0]).type(torch.DoubleTensor).numpy()
+        assert np.array_equal(jB, g["jitterB%d" % k]) and np.array_equal(jK, g["jitterK%d" % k])
+        y = g["y%d" % k]
+        v = O.multivariate_normal_logpdf1(y, np.zeros_like(y), g["B%d" % k], g["K%d" % k], float(g["sig2_%d" % k]), jB, jK)
+        assert relerr(v, g["logpdf1_%d" % k]) < 1e-9, (k, v, g["logpdf1_%d" % k])
+        v0 = O.multivariate_normal_logpdf0(y, np.zeros_like(y), g["B%d" % k], g["K%d" % k], float(g["sig2_%d" % k]))
+        assert relerr(v0, g["logpdf0_%d" % k]) < 1e-9
+        assert v != v0                       # the jitter does move the value (it is not a no-op in the fixture)
+
+
+def test_config4_subjects_at_full_size():
+    """BASELINE config 4's per-GPU shape: 8 subjects, N = 1024, D = 3, mpisim hyper-parameters; reference values and
+    autograd gradients at the benchmark's evaluation point and at the generating parameters."""
+    g = golden("cfg4_subjects_N1024_M3")
+    h = hyper_dict(g["hyper"], SVC_KEYS)
+    for s in range(g["xs"].shape[0]):
+        for pk, ok, gk in (("pars", "out", "grad"), ("pars_true", "out_true", "grad_true")):
+            if pk == "pars_true" and s % 4:
+                continue                   # every subject at the benchmark point, two of them also at the truth
+            r, grad = O.nlogpos_obj_SVC(g[pk][s], g["Ys"][s], g["xs"][s], **h, verbose=True, formulation="cholesky", grad=True)
+            assert relerr(r[0], g[ok][s][0]) < VAL_TOL, (s, pk, r, g[ok][s])
+            assert relerr(r[1], g[ok][s][1]) < 1e-9 and relerr(r[4], g[ok][s][4]) < 1e-12
+            assert prior_term_err(r[2:4], g[ok][s][2:4], g["xs"].shape[1]) < VAL_TOL
+            assert vec_relerr(grad, g[gk][s]) < GRAD_TOL
 
 
 @pytest.mark.parametrize("name", golden_names("sep_"))
