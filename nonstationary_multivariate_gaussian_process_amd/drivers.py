@@ -141,7 +141,8 @@ class HMCSampler:
             except RuntimeError:                  # covariance left the positive definite cone: reject
                 U1, H1 = np.inf, np.inf
             dH = H1 - H0
-            acc = np.isfinite(dH) and (np.log(self.rng.random()) < -dH)
+            u = np.log(self.rng.random())         # drawn every iteration: the stream does not depend on the outcome
+            acc = bool(np.isfinite(dH) and (u < -dH))
             if acc:
                 q, U, g = q1, U1, g1
                 accepted += 1
@@ -163,41 +164,24 @@ def sampler(**kw):
     return HMCSampler(**kw)
 
 
-class BatchedHMC:
-    """B independent HMC chains of one subject advanced in lock-step on the GPU.
+class LockStepHMC:
+    """B independent HMC chains advanced in lock-step: every leapfrog step asks ``potential_and_grad(q [B, P])`` for the
+    potentials U [B] and gradients [B, P] of ALL chains at once (U = inf marks a chain whose potential is undefined at
+    that point, e.g. a covariance outside the positive definite cone).  Identity mass matrix.  Chain b draws from its own
+    generator in the order of :class:`HMCSampler` (momentum, then the uniform of the accept test), so a chain reproduces
+    the single-chain sampler started from the same state.  Subclasses provide ``potential_and_grad``."""
 
-    Every leapfrog step evaluates the potential and its gradient for ALL chains with one batched launch sequence
-    (``nmgp_svc_batch_eval(want_grad=1)``): the chains are the reference's embarrassingly-parallel unit
-    (one process each there, ``Nonseparable_model_mpisim.py:305-306``); here they share the GPU's launch latency.
-    Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
-    """
-
-    def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None):
-        from . import _lib
-        self.ctx = ctx if ctx is not None else _lib.default_context()
+    def __init__(self, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None):
         self.q = np.array(init_positions, dtype=np.float64, copy=True)
         if self.q.ndim != 2:
             raise ValueError("init_positions must be [B, P]")
         self.B, self.P = self.q.shape
-        keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
-        self.hyper = np.array([float(hyper_pars[k]) for k in keys])
-        self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
-        self.ctx.svc_batch_alloc(self.B)
         self.eps = float(step_size)
         self.L = int(num_steps_in_leap)
         self.rngs = [np.random.default_rng(None if seed is None else seed + b) for b in range(self.B)]
 
     def potential_and_grad(self, q):
-        """U [B] and dU/dq [B, P]; a chain whose covariance is not positive definite gets U = inf."""
-        self.ctx.svc_batch_set_pars(q)
-        self.ctx.svc_batch_eval(self.hyper, True, want_grad=True)
-        out, status = self.ctx.svc_batch_fetch()
-        g = self.ctx.svc_batch_fetch_grad()
-        U = out[:, 0].copy()
-        bad = status != 0
-        U[bad] = np.inf
-        g[bad] = 0.0
-        return U, g
+        raise NotImplementedError
 
     def run(self, sample_size):
         B, P = self.B, self.P
@@ -211,10 +195,16 @@ class BatchedHMC:
             q1 = self.q.copy()
             p1 = p0 - 0.5 * self.eps * g
             U1, g1 = U, g
+            # A chain whose potential is undefined at ANY intermediate point has left the leapfrog map (its momentum kick
+            # was skipped there): it must be rejected even if the trajectory comes back to a valid point, exactly as
+            # HMCSampler.leapfrog returns inf at the first non-finite potential.
+            failed = np.zeros(B, dtype=bool)
             for step in range(self.L):
                 q1 = q1 + self.eps * p1
                 U1, g1 = self.potential_and_grad(q1)
+                failed |= ~np.isfinite(U1)
                 p1 = p1 - (self.eps if step < self.L - 1 else 0.5 * self.eps) * g1
+            U1 = np.where(failed, np.inf, U1)
             H1 = U1 + 0.5 * (p1 * p1).sum(1)
             dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])
@@ -226,3 +216,34 @@ class BatchedHMC:
             energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
             samples[it] = self.q
         return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
+
+
+class BatchedHMC(LockStepHMC):
+    """B independent HMC chains of one subject advanced in lock-step on the GPU.
+
+    Every leapfrog step evaluates the potential and its gradient for ALL chains with one batched launch sequence
+    (``nmgp_svc_batch_eval(want_grad=1)``): the chains are the reference's embarrassingly-parallel unit
+    (one process each there, ``Nonseparable_model_mpisim.py:305-306``); here they share the GPU's launch latency.
+    Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
+    """
+
+    def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None):
+        from . import _lib
+        super().__init__(init_positions, step_size, num_steps_in_leap, seed)
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
+        self.hyper = np.array([float(hyper_pars[k]) for k in keys])
+        self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
+        self.ctx.svc_batch_alloc(self.B)
+
+    def potential_and_grad(self, q):
+        """U [B] and dU/dq [B, P]; a chain whose covariance is not positive definite gets U = inf."""
+        self.ctx.svc_batch_set_pars(q)
+        self.ctx.svc_batch_eval(self.hyper, True, want_grad=True)
+        out, status = self.ctx.svc_batch_fetch()
+        g = self.ctx.svc_batch_fetch_grad()
+        U = out[:, 0].copy()
+        bad = status != 0
+        U[bad] = np.inf
+        g[bad] = 0.0
+        return U, g

@@ -56,3 +56,41 @@ def prior_term_err(a, b, N):
     b = np.asarray(b, dtype=np.float64)
     scale = np.maximum(np.abs(b), 0.5 * N * abs(np.log(1e-6)))
     return float(np.max(np.abs(a - b) / scale))
+
+
+# ---- achieved-parity table ------------------------------------------------------------------------------
+# GPU parity tests record the error they achieved against every golden vector / oracle value; at the end of a session
+# that recorded anything the table is written to gpurun_out/parity_<round>.json (copied to profiles/ and committed), so a
+# drift towards the tolerance is visible long before it fails a test.
+_PARITY = []
+
+
+def record_parity(case, **errs):
+    """errs: name -> achieved error, or name -> (achieved, tolerance)."""
+    row = {"case": case}
+    for k, v in errs.items():
+        if isinstance(v, tuple):
+            row[k] = float(v[0])
+            row[k + "_tol"] = float(v[1])
+        else:
+            row[k] = float(v)
+    _PARITY.append(row)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "parity_%s.json" % os.environ.get("NMGP_ROUND", "r02"))
+    worst = {}
+    for row in _PARITY:
+        for k, v in row.items():
+            if k != "case" and not k.endswith("_tol") and (k + "_tol") in row and row[k + "_tol"] > 0:
+                frac = v / row[k + "_tol"]
+                if frac > worst.get(k, (0.0, None))[0]:
+                    worst[k] = (frac, row["case"])
+    with open(path, "w") as f:
+        json.dump({"exitstatus": int(exitstatus), "rows": _PARITY,
+                   "worst_fraction_of_tolerance": {k: {"frac": v[0], "case": v[1]} for k, v in worst.items()}}, f, indent=1)
