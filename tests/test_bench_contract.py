@@ -48,4 +48,14 @@ def test_bench_prints_one_valid_json_line(extra):
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12 and "traffic" in rl
     cb = rec["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["reference_formulation"]["value"] > 0 and "inverse + logdet" in cb["reference_formulation"]["sample"]
+    B = int(extra[extra.index("--chains") + 1])
+    assert rec["config"]["chains_total"] == B and rec["config"]["chains_ok"] == B      # every chain is reduced, not chain 0 only
+    if "--grad" not in extra:
+        gr = rec["grad"]
+        assert gr["value"] > 0 and gr["chains_ok"] == B and gr["roofline"]["bound"] == "mfma" and gr["grad_norm_chain0"] > 0
+        assert abs(gr["roofline"]["frac"] - gr["roofline"]["achieved"] / gr["roofline"]["peak"]) < 1e-12
+    else:
+        assert "grad" not in rec and "gradients" in rec["config"]["host_reads_per_step"]
+    assert rl["traffic"] is None and rl["traffic_note"]          # no PMC measurement exists for this toy size
     assert np.isfinite(rec["value"]) and rec["value"] > 0

@@ -1,0 +1,172 @@
+"""bench.py's N>1 control flow (rank -> subject/chains, warm-up, barrier-bracketed timed steps, max over ranks, the ONE
+reduction, rank 0's JSON line) driven by two gloo ranks on CPU with the CPU oracle as evaluator.  The code under test is
+bench.run_chains / bench.run_subjects / bench.main themselves -- only the backend object (device, process-group backend,
+evaluator) is swapped, exactly the seam bench.py documents.  Reference pattern: Nonseparable_model_mpisim.py:41-43,305-306
+(rank -> data file, no communication)."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+N, M = 14, 2
+
+
+class OracleEvaluator:
+    """step(want_grad) -> (out [B, 5], status [B]) like bench.HipChains / bench.HipSubjects, computed by the CPU oracle."""
+
+    def __init__(self, units, hyper, fail=()):
+        self.units = units              # list of (x, Y, pars)
+        self.hyper = hyper
+        self.fail = set(fail)
+        self.grads = None
+        self.steps_done = 0
+
+    def step(self, want_grad):
+        from oracle import nmgp_oracle as O
+        outs, st, gs = [], [], []
+        for k, (x, Y, p) in enumerate(self.units):
+            if k in self.fail:
+                outs.append(np.full(5, np.nan))
+                st.append(7)
+                gs.append(np.zeros_like(p))
+                continue
+            r = O.nlogpos_obj_SVC(p, Y, x, **self.hyper, verbose=True, grad=want_grad)
+            if want_grad:
+                r, g = r
+                gs.append(g)
+            outs.append(np.array(r))
+            st.append(0)
+        self.grads = np.stack(gs) if want_grad else None
+        self.steps_done += 1
+        return np.stack(outs), np.array(st, dtype=np.int32)
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class GlooOracleBackend:
+    device = "cpu"
+
+    def __init__(self, fail_subject=None):
+        self.fail_subject = fail_subject
+        self.evaluators = []
+
+    def init_dist(self, rank, world):
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def sync(self):
+        pass
+
+    def chains(self, d, allp, hv, groups):
+        from nonstationary_multivariate_gaussian_process_amd import sim
+        ev = OracleEvaluator([(d["x"], d["Y"], p) for p in allp], sim.HYPER_SVC)
+        self.evaluators.append(ev)
+        return ev
+
+    def subjects(self, subs, pars, hv):
+        from nonstationary_multivariate_gaussian_process_amd import sim
+        fail = [k for k, d in enumerate(subs) if self.fail_subject is not None and d.get("seed") == self.fail_subject]
+        ev = OracleEvaluator([(d["x"], d["Y"], p) for d, p in zip(subs, pars)], sim.HYPER_SVC_MPISIM, fail)
+        self.evaluators.append(ev)
+        return ev
+
+
+def _worker(rank, world, port, argv, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    import bench
+    from test_bench_flow_gloo import GlooOracleBackend
+    be = GlooOracleBackend()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rec, stats, table = bench.main(argv, backend=be)
+    q.put((rank, buf.getvalue(), stats, table, [e.steps_done for e in be.evaluators]))
+
+
+def _run(argv, world=2):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    return got
+
+
+def test_chain_workload_two_ranks():
+    """world = 2, B = 3 chains per rank: one JSON line from rank 0 only, value = steps * world * B / time, the reduction
+    covers ALL chains of both ranks (chains_ok == B * world) and every rank holds the same table."""
+    B, steps, warm, gsteps = 3, 2, 1, 1
+    got = _run(["--gpus", "2", "--steps", str(steps), "--warmup", str(warm), "--N", str(N), "--M", str(M), "--chains",
+                str(B), "--grad-steps", str(gsteps), "--no-cpu-baseline"])
+    lines0 = [ln for ln in got[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in got[1][1].splitlines() if ln.startswith("{")]
+    rec = json.loads(lines0[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == steps and rec["warmup"] == warm and rec["scaling"] == "weak"
+    assert rec["unit"] == "evals/s" and rec["dtype"] == "f64" and rec["vs_baseline"] is None
+    assert abs(rec["value"] - steps * 2 * B / (rec["ms_per_step"] * 1e-3 * steps)) < 1e-9 * rec["value"]
+    cfg = rec["config"]
+    assert cfg["chains_total"] == 2 * B and cfg["chains_ok"] == 2 * B and cfg["chains_failed"] == 0
+    assert cfg["chain_table_rows"] == 2 * B
+    assert "cpu_baseline" not in rec                       # rank 0 at N = 1 only
+    assert rec["grad"]["steps"] == gsteps and rec["grad"]["chains_ok"] == B and rec["grad"]["value"] > 0
+    # warm-up + timed + (no profiling pass on this backend) + grad warm-up + grad steps
+    assert got[0][4] == [warm + steps + 1 + gsteps] and got[1][4] == [warm + steps + 1 + gsteps]
+    stats0, table0 = got[0][2], got[0][3]
+    assert np.array_equal(stats0, got[1][2]) and np.array_equal(table0, got[1][3])
+    assert table0.shape == (2 * B, 8) and list(table0[:, 0]) == list(range(2 * B)) and np.all(table0[:, 2] == steps)
+    # rows equal independent oracle evaluations of (rank's subject, chain's parameters)
+    sys.path.insert(0, ROOT)
+    import bench
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from oracle import nmgp_oracle as O
+    tot = 0.0
+    for rank in range(2):
+        d = sim.simulate_nonseparable(N, M, seed=2222 + rank)
+        allp = bench.chain_parameters(sim, d, B)
+        for b in range(B):
+            ref = np.array(O.nlogpos_obj_SVC(allp[b], d["Y"], d["x"], **sim.HYPER_SVC, verbose=True))
+            assert np.array_equal(table0[rank * B + b, 3:8], ref)
+            tot += ref[0]
+    assert abs(cfg["sum_neglog_all_chains"] - tot) < 1e-9 * abs(tot)
+
+
+def test_subject_workload_two_ranks():
+    """Config-4 pattern at world = 2, 3 subjects per rank: subject s on rank s mod world with seed s, table ordered by
+    subject id on every rank."""
+    got = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--N", str(N), "--M", str(M), "--workload", "subjects",
+                "--subjects-per-gpu", "3"])
+    rec = json.loads([ln for ln in got[0][1].splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["config"]["subjects_total"] == 6 and rec["config"]["subjects_ok"] == 6
+    assert rec["config"]["subject_table_rows"] == 6
+    table = got[0][3]
+    assert np.array_equal(table, got[1][3]) and list(table[:, 0]) == list(range(6))
+    sys.path.insert(0, ROOT)
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from oracle import nmgp_oracle as O
+    for s in range(6):
+        d = sim.simulate_nonseparable(N, M, seed=s)
+        ref = np.array(O.nlogpos_obj_SVC(sim.perturb(d["pars_true"], 0.05, 0.7), d["Y"], d["x"], **sim.HYPER_SVC_MPISIM,
+                                         verbose=True))
+        assert np.array_equal(table[s, 3:8], ref)
