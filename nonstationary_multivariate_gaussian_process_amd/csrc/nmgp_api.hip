@@ -27,6 +27,21 @@ int nmgp_fail(nmgp_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- launch-error bookkeeping (NMGP_LAUNCH, nmgp_internal.h) -----------------------------------------
+static thread_local char g_launch_err[256] = {0};
+
+void nmgp_note_launch_error(const char* kernel, hipError_t e) {
+    if (g_launch_err[0]) return;                 // keep the first one: later launches usually fail because of it
+    snprintf(g_launch_err, sizeof(g_launch_err), "launch of %s was rejected: %s", kernel, hipGetErrorString(e));
+}
+
+int nmgp_take_launch_error(nmgp_ctx* c) {
+    if (!g_launch_err[0]) return 0;
+    int rc = nmgp_fail(c, NMGP_E_HIP, "%s", g_launch_err);
+    g_launch_err[0] = 0;
+    return rc;
+}
+
 // ---- profiling helpers ---------------------------------------------------------------------------
 typedef NmgpStage StageScope;
 NmgpStage::NmgpStage(nmgp_ctx* ctx, int st, hipStream_t s, double work, double bytes) : c(ctx), stage(st), stream(s) {
@@ -120,15 +135,8 @@ bool nmgp_poison() {
     return on;
 }
 
-// leading dimension (doubles) of a column-major factorisation buffer with `rows` rows: a multiple of 16 (64-byte columns);
-// NMGP_LD_EXTRA=<k> adds k doubles (experiments on how the column stride meets the HBM channel interleaving)
-size_t nmgp_ld(size_t rows) {
-    static const size_t extra = [] {
-        const char* e = std::getenv("NMGP_LD_EXTRA");
-        return e ? (size_t)std::atoi(e) : (size_t)0;
-    }();
-    return ((rows + 15) / 16) * 16 + extra;
-}
+// leading dimension (doubles) of a column-major factorisation buffer with `rows` rows: a multiple of 16 (64-byte columns)
+size_t nmgp_ld(size_t rows) { return ((rows + 15) / 16) * 16; }
 
 int nmgp_scratch_get(nmgp_ctx* c, int slot, size_t nelem, double** out) {
     DevBuf& b = c->scratch[slot];
@@ -419,6 +427,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         }
     }
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    if (nmgp_poison()) HIP_TRY(c, hipMemsetAsync(sc + SC_OUT, 0xFF, 8 * sizeof(double), s));   // stale results must not survive
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->d_pars, N, M, c->d_ell, c->d_Lv);
@@ -534,7 +543,7 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     }
     c->last_want_grad = want_grad != 0;
     c->last_kind = 1;
-    return 0;
+    return nmgp_take_launch_error(c);
 }
 
 extern "C" int nmgp_svc_set_pars(nmgp_ctx* c, const double* pars) {
@@ -566,6 +575,7 @@ extern "C" int nmgp_svc_fetch(nmgp_ctx* c, double out5[5], double* grad) {
     if (grad)
         HIP_TRY(c, hipMemcpyAsync(grad, c->d_grad, (size_t)c->P_svc * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    NMGP_TRY(nmgp_take_launch_error(c));
     if (c->h_info[0] != 0)
         return nmgp_fail(c, c->h_info[0], "Cholesky of the %d x %d covariance failed: leading minor %d is not positive "
                          "definite", c->n, c->n, c->h_info[0]);
@@ -762,6 +772,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
     }
     HIP_TRY(c, hipMemsetAsync(c->b_info, 0, (size_t)B * sizeof(int), s));
+    if (nmgp_poison()) HIP_TRY(c, hipMemsetAsync(c->b_scal, 0xFF, (size_t)B * 16 * sizeof(double), s));
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
@@ -859,7 +870,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     }
     c->b_last_grad = want_grad != 0;
     c->last_kind = 2;
-    return 0;
+    return nmgp_take_launch_error(c);
 }
 
 extern "C" double* nmgp_svc_batch_grad_dev(nmgp_ctx* c) { return c ? c->b_grad : nullptr; }
@@ -890,6 +901,7 @@ extern "C" int nmgp_svc_batch_fetch(nmgp_ctx* c, double* out, int* status) {
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(hi.data(), c->b_info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    NMGP_TRY(nmgp_take_launch_error(c));
     for (int z = 0; z < B; ++z) {
         int st = hi[z];
         for (int k = 0; k < 5; ++k) out[(size_t)z * 5 + k] = h[(size_t)z * 16 + 8 + k];
@@ -955,6 +967,7 @@ extern "C" int nmgp_cholesky(nmgp_ctx* c, const double* A, int n, const double* 
     if (rhs) HIP_TRY(c, hipMemcpyAsync(out_z, dv + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(c->h_info + 5, c->d_info + 5, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    NMGP_TRY(nmgp_take_launch_error(c));
     if (c->h_info[5] != 0)
         return nmgp_fail(c, c->h_info[5], "matrix is not positive definite (leading minor %d)", c->h_info[5]);
     return 0;
@@ -970,7 +983,7 @@ static int upload(nmgp_ctx* c, int slot, const double* h, size_t nelem, double**
 static int download(nmgp_ctx* c, double* h, const double* d, size_t nelem) {
     HIP_TRY(c, hipMemcpyAsync(h, d, nelem * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return nmgp_take_launch_error(c);
 }
 
 extern "C" int nmgp_pairwise_distances(nmgp_ctx* c, const double* x1, int n1, const double* x2, int n2, int d,

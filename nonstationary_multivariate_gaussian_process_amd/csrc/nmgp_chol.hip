@@ -335,7 +335,9 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
 template <int NWJ, int BK>
 __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int mrows,
                                                int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
-                                               int nbatch) {
+                                               int nbatch, int bx, int by, int bz0, double* sAb, double* sBb) {
+    // (bx, by, bz0) = the launch's blockIdx, or the tile a fused kernel assigns to this workgroup; sAb / sBb: 2 * BK * SY_LD
+    // doubles of LDS each
     const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
     const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
     const int yrow = nyr ? mrows : -1;
@@ -345,10 +347,10 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
     constexpr int NQ = (64 * BK) / NT;     // 16-byte loads per thread per operand and k-step
     constexpr int CGS = NT / 64;           // k-columns covered per load round
-    __shared__ double sA[2][BK * SY_LD];
-    __shared__ double sB[2][BK * SY_LD];
-    int bi = blockIdx.x, bj = blockIdx.y;
-    int bz = blockIdx.z;
+    double (*sA)[BK * SY_LD] = reinterpret_cast<double (*)[BK * SY_LD]>(sAb);
+    double (*sB)[BK * SY_LD] = reinterpret_cast<double (*)[BK * SY_LD]>(sBb);
+    int bi = bx, bj = by;
+    int bz = bz0;
     if (swz) {
         // XCD-aware tile order.  Workgroups are dealt round-robin and IN ORDER over the 8 XCDs (t and t + 8 share an
         // L2), so every XCD must receive the same work per round or the others idle behind it: the VALID tiles of all
@@ -359,7 +361,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         // Short launches (swz < 0, -swz = valid tiles per matrix) keep the compact enumeration but deal consecutive
         // tiles to consecutive XCDs: no early-exit workgroups, and no correlation between XCD and tile row (with a plain
         // grid of 8 k tile rows XCD x owned tile row x: 1 tile for XCD 0, 8 for XCD 7).
-        const int t = blockIdx.x, q = t >> 3;
+        const int t = bx, q = t >> 3;
         const int tiles_pm = swz > 0 ? swz : -swz;
         const long long g = swz > 0 ? ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63) : (long long)t;   // compact tile index
         bz = (int)(g / tiles_pm);
@@ -523,120 +525,84 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     }
 }
 
-// C[i, j] -= sum_k A[i, k] A[j, k] on the lower trapezoid (see syrk_tile_body), plus an OPTIONAL fused diagonal step
-// (pnb > 0, NMGP_FUSE_POTF2=1; off by default, see potrf_lower): the leading 64x64 block of the updated C is the next
-// block the factorisation needs, so the workgroup that owned tile (0, 0) -- dispatched first -- can factor it right
-// here while the other tiles of the launch are still running.
-// The tail re-derives the tile from blockIdx instead of keeping it alive across the tile body (register pressure).
-template <int NWJ, int BK>
-__global__ __launch_bounds__(128 * NWJ, (BK > 16 ? NWJ / 2 : NWJ)) void k_syrk_lower(const double* __restrict__ A, int lda,
-                                                                 double* __restrict__ C, int ldc, int mrows, int ncols,
-                                                                 int K, long long bstride, long long cstride, int ktri,
-                                                                 int swz, int nbatch, int* __restrict__ pinfo, int pgoff,
-                                                                 int pnb, int pistride) {
-    syrk_tile_body<NWJ, BK>(A, lda, C, ldc, mrows, ncols, K, bstride, cstride, ktri, swz, nbatch);
-    if (pnb <= 0) return;
-    int bz;
-    if (swz) {
-        // tile (0, 0) of matrix bz is compact tile index g = bz * swz: g = (chunk * 64 + within), chunk = 8 (q >> 6) + (t & 7)
-        const int t = blockIdx.x, q = t >> 3;
-        const int tiles_pm = swz > 0 ? swz : -swz;
-        const long long g = swz > 0 ? ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63) : (long long)t;
-        bz = (int)(g / tiles_pm);
-        if (bz >= nbatch || g != (long long)bz * tiles_pm) return;
-    } else {
-        if (blockIdx.x != 0 || blockIdx.y != 0) return;
-        bz = blockIdx.z;
-    }
-    bz = __builtin_amdgcn_readfirstlane(bz);
-    __shared__ double colbuf[2][64];
-    __shared__ double pivs[64];
-    __threadfence();
-    __syncthreads();
-    potf2_body(C + (size_t)bz * cstride, ldc, pnb, pinfo + (size_t)bz * pistride, pgoff, threadIdx.x, colbuf, pivs);
+// C[i, j] -= sum_k A[i, k] A[j, k] on the lower trapezoid (see syrk_tile_body): 128x128 tiles, 8 waves of 64x32.
+__global__ __launch_bounds__(512, 4) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc,
+                                                        int mrows, int ncols, int K, long long bstride, long long cstride,
+                                                        int ktri, int swz, int nbatch) {
+    __shared__ double sA[2 * SY_BK * SY_LD];
+    __shared__ double sB[2 * SY_BK * SY_LD];
+    syrk_tile_body<4, SY_BK>(A, lda, C, ldc, mrows, ncols, K, bstride, cstride, ktri, swz, nbatch, blockIdx.x, blockIdx.y,
+                             blockIdx.z, sA, sB);
 }
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
-static int g_syrk_nwj = 0;     // 0 = not read yet; NMGP_SYRK_WAVES=4|8 selects the workgroup shape (default 8)
+static int g_syrk_env = 0;     // 0 = environment not read yet
 static int g_syrk_swz = 1;     // NMGP_SYRK_SWIZZLE=0 disables the XCD-aware tile order
 static int g_syrk_half = 1;    // NMGP_SYRK_HALF=0: see syrk_tile_body
 static int g_syrk_yrow = 1;    // NMGP_SYRK_YROW=0: the right-hand-side row keeps its own (masked) tile row
-static int g_syrk_bk = 16;     // NMGP_SYRK_BK=16|32 (k-panel depth; 32 needs 147 KB of LDS: one workgroup per CU)
 
-// fused-potf2 state of the factorisation in progress (set by potrf_lower)
-struct PotfFuse {
-    bool on = false;
-    int* info = nullptr;
-    int istride = 0;
-    int n = 0;
-    int done_at = -1;        // global column whose diagonal block the last SYRK launch has already factored
+// launch geometry of one trapezoid update: grid, tile-order mode and kernel flags (shared with the fused panel step)
+struct SyrkPlan {
+    dim3 grid;
+    int swz = 0;
+    int kflags = 0;
+    int mrows = 0;       // rows covered by full/partial tiles (the rows below, if any, ride in the diagonal tiles)
+    int tiles = 0;       // valid lower-trapezoid tiles per matrix
 };
-static thread_local PotfFuse g_fuse;
 
-void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride, int ktri, int next_c) {
-    if (mrows <= 0 || ncols <= 0 || K <= 0) return;
-    if (g_syrk_nwj == 0) {
-        const char* e = std::getenv("NMGP_SYRK_WAVES");
-        g_syrk_nwj = (e && std::atoi(e) == 4) ? 2 : 4;
-        const char* b = std::getenv("NMGP_SYRK_BK");
-        g_syrk_bk = (b && std::atoi(b) == 32) ? 32 : 16;
+static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int batch, int ktri, bool compact_only) {
+    if (!g_syrk_env) {
+        g_syrk_env = 1;
         if (const char* z = std::getenv("NMGP_SYRK_SWIZZLE")) g_syrk_swz = std::atoi(z) != 0;
         if (const char* z = std::getenv("NMGP_SYRK_HALF")) g_syrk_half = std::atoi(z) != 0;
         if (const char* z = std::getenv("NMGP_SYRK_YROW")) g_syrk_yrow = std::atoi(z) != 0;
     }
+    SyrkPlan pl;
     // evaluations carry a few extra rows below a whole number of tiles (value: the right-hand side; gradient: two more rows
     // of L^-T): the diagonal tiles take them along (syrk_tile_fast) and the masked tile row disappears.  Needs every tile
     // of the launch on the fast path.
     int yflag = 0;
-    const int mrows_alg = mrows;                        // rows of the update as the caller stated it (work accounting)
     const int nyr = mrows % SY_BM;                      // rows below the last full tile
-    if (g_syrk_yrow && g_syrk_nwj == 4 && g_syrk_bk == 16 && !ktri && mrows > SY_BM && nyr >= 1 && nyr <= 16 &&
-        ncols % SY_BM == 0 && (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL && (lda & 1) == 0 && (ldc & 1) == 0) {
+    if (g_syrk_yrow && !ktri && mrows > SY_BM && nyr >= 1 && nyr <= 16 && ncols % SY_BM == 0 && (K & 31) == 0 &&
+        (long long)(K + 16) * lda * 8 < 0x7fff0000LL && (lda & 1) == 0 && (ldc & 1) == 0) {
         yflag = nyr << 2;
         mrows -= nyr;
     }
-    dim3 grid(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
-    int swz = 0;
-    if (g_syrk_swz && grid.y >= 2) {
-        const int gx = grid.x, gy = grid.y;
-        int tiles = 0;                                  // valid (lower-trapezoid) tiles per matrix
-        for (int c0 = 0; c0 < gy; c0 += SY_SB) {
-            const int W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
-            tiles += W * (W + 1) / 2 + (gx - c0 - W) * W;
-        }
-        const long long total = (long long)tiles * batch;
+    pl.mrows = mrows;
+    pl.grid = dim3(cdiv_c(mrows, SY_BM), cdiv_c(ncols, SY_BM), batch);
+    const int gx = pl.grid.x, gy = pl.grid.y;
+    for (int c0 = 0; c0 < gy; c0 += SY_SB) {            // valid (lower-trapezoid) tiles per matrix
+        const int W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
+        pl.tiles += W * (W + 1) / 2 + (gx - c0 - W) * W;
+    }
+    if (compact_only || (g_syrk_swz && gy >= 2)) {
+        const long long total = (long long)pl.tiles * batch;
         const long long rounds = (total + 511) / 512;   // 8 XCDs x 64 tiles per round
-        if (rounds >= 16) {                             // chunks of 64 tiles per XCD (L2 reuse)
-            grid = dim3((unsigned)(rounds * 512), 1, 1);
-            swz = tiles;
+        if (rounds >= 16 && !compact_only) {            // chunks of 64 tiles per XCD (L2 reuse)
+            pl.grid = dim3((unsigned)(rounds * 512), 1, 1);
+            pl.swz = pl.tiles;
         } else {                                        // fewer rounds: the chunking's tail would cost more than it gains
-            grid = dim3((unsigned)total, 1, 1);
-            swz = -tiles;
+            pl.grid = dim3((unsigned)total, 1, 1);
+            pl.swz = -pl.tiles;
         }
     }
+    pl.kflags = (ktri ? 1 : 0) | (g_syrk_half ? 0 : 2) | yflag;
+    return pl;
+}
+
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
+                long long bstride, long long cstride, int ktri) {
+    if (mrows <= 0 || ncols <= 0 || K <= 0) return;
+    const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false);
     const long long cs = cstride < 0 ? bstride : cstride;
-    int* pinfo = nullptr;
-    int pnb = 0;
-    if (g_fuse.on && next_c >= 0 && next_c < g_fuse.n) {
-        pinfo = g_fuse.info;
-        pnb = g_fuse.n - next_c < 64 ? g_fuse.n - next_c : 64;
-        if (pnb > ncols) pnb = 0;                 // (cannot happen in the schedules below; keeps the kernel's contract)
-        else g_fuse.done_at = next_c;
-    }
-    const int kflags = (ktri ? 1 : 0) | (g_syrk_half ? 0 : 2) | yflag;
     void* tok = nullptr;
     if (g_hook && g_hook->begin) {
         // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
-        const double elems = (double)ncols * mrows_alg - 0.5 * (double)ncols * (ncols - 1);
-        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows_alg * K));
+        const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
+        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
     }
-    if (g_syrk_nwj == 2)
-        hipLaunchKernelGGL((k_syrk_lower<2, 16>), grid, dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
-    else if (g_syrk_bk == 32)
-        hipLaunchKernelGGL((k_syrk_lower<4, 32>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
-    else
-        hipLaunchKernelGGL((k_syrk_lower<4, 16>), grid, dim3(512), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, cs, kflags, swz, batch, pinfo, next_c, pnb, g_fuse.istride);
+    NMGP_LAUNCH(k_syrk_lower, pl.grid, dim3(512), 0, s, A, lda, C, ldc, pl.mrows, ncols, K, bstride, cs, pl.kflags,
+                       pl.swz, batch);
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 
@@ -769,26 +735,21 @@ __device__ __forceinline__ void potf2x_steps4(double (&a)[4], double (&e)[4], do
     potf2x_step<KC, 3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
 }
 
-__global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
-                                                    int goff, long long bstride, int istride, int xbar) {
-    A += (size_t)blockIdx.x * bstride;
-    info += (size_t)blockIdx.x * istride;
-    __shared__ double S[64 * PB_LD];            // S[col * PB_LD + row]
-    __shared__ double Einv[4][16][17];          // inv(L_qq)[row][col] of the four diagonal blocks
-    __shared__ double colbuf[2][16];
-    __shared__ double rowbuf[2][16];
-    __shared__ double pivs[64];
+// LDS working set of the blocked 64x64 diagonal factorisation (k_potf2_64b and the fused panel step)
+struct Potf2Lds {
+    double S[64 * PB_LD];            // S[col * PB_LD + row]
+    double Einv[4][16][17];          // inv(L_qq)[row][col] of the four diagonal blocks
+    double colbuf[2][16];
+    double rowbuf[2][16];
+    double pivs[64];
+};
+
+// Factor the 64x64 block held in P.S (lower triangle valid, strict upper zero).  Called by EVERY thread of the workgroup
+// (the barriers are workgroup barriers); threads 0..255 do the work, any further waves only take part in the barriers.
+// On return (after the trailing barrier) P.S holds L and P.Einv the inverted diagonal 16x16 blocks.
+__device__ __forceinline__ void potf2b_core(Potf2Lds& P, int* __restrict__ info, int goff, int xbar) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = tid + 256 * k;
-        const int r = idx & 63, c = idx >> 6;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
-        S[c * PB_LD + r] = v;
-    }
-    __syncthreads();
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         if (w == 0 && xbar) {
@@ -798,21 +759,21 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cc = 4 * kk + g;
-                a[kk] = (cc <= r) ? S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
+                a[kk] = (cc <= r) ? P.S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
                 e[kk] = (cc == r) ? 1.0 : 0.0;
             }
-            double* Sqq = &S[(16 * q) * PB_LD + 16 * q];
-            potf2x_steps4<0>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<1>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<2>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
+            double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
+            potf2x_steps4<0>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<1>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<2>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2x_steps4<3>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
             __builtin_amdgcn_wave_barrier();
-            const double sr = rsqrt(pivs[16 * q + r]);
+            const double sr = rsqrt(P.pivs[16 * q + r]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cc = 4 * kk + g;
-                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(pivs[16 * q + cc]);
-                Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
+                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(P.pivs[16 * q + cc]);
+                P.Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
             }
         } else if (w == 0) {
             // (A) thread (r, g) = (lane & 15, lane >> 4) keeps S_qq[r][4 kk + g] and E[r][4 kk + g], kk = 0..3
@@ -821,27 +782,27 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cc = 4 * kk + g;
-                a[kk] = (cc <= r) ? S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
+                a[kk] = (cc <= r) ? P.S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
                 e[kk] = (cc == r) ? 1.0 : 0.0;
             }
-            if (g == 0) colbuf[0][r] = a[0];
+            if (g == 0) P.colbuf[0][r] = a[0];
             if (r == 0) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) rowbuf[0][4 * kk + g] = e[kk];
+                for (int kk = 0; kk < 4; ++kk) P.rowbuf[0][4 * kk + g] = e[kk];
             }
             __builtin_amdgcn_wave_barrier();
-            double* Sqq = &S[(16 * q) * PB_LD + 16 * q];
-            potf2b_steps4<0>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<1>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<2>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<3>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
+            double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
+            potf2b_steps4<0>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<1>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<2>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
+            potf2b_steps4<3>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
             // L_qq = S~ D^-1/2 (column scaling of the unscaled columns the steps left in S), inv(L_qq) = D^-1/2 E (rows)
-            const double sr = rsqrt(pivs[16 * q + r]);
+            const double sr = rsqrt(P.pivs[16 * q + r]);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cc = 4 * kk + g;
-                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(pivs[16 * q + cc]);
-                Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
+                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(P.pivs[16 * q + cc]);
+                P.Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
             }
         }
         __syncthreads();
@@ -853,13 +814,13 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
                 v4d x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const double av = Einv[q][l15][4 * kk + l4];                                   // A: row c' = l15, k = c
-                    const double bv = S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];            // B: k = c, col = row r
+                    const double av = P.Einv[q][l15][4 * kk + l4];                                   // A: row c' = l15, k = c
+                    const double bv = P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];            // B: k = c, col = row r
                     x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
                 }
                 // all four k-slices are read before any of them is overwritten (same wave, in order)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) S[(16 * q + l4 + 4 * reg) * PB_LD + 16 * i + l15] = x[reg];
+                for (int reg = 0; reg < 4; ++reg) P.S[(16 * q + l4 + 4 * reg) * PB_LD + 16 * i + l15] = x[reg];
             }
         }
         __syncthreads();
@@ -871,30 +832,50 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
                     if ((t & 3) != w) continue;
                     v4d acc;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[reg] = S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15];
+                    for (int reg = 0; reg < 4; ++reg) acc[reg] = P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15];
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
-                        const double av = -S[(16 * q + 4 * kk + l4) * PB_LD + 16 * j + l15];      // A: row of X_j
-                        const double bv = S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];       // B: row of X_i
+                        const double av = -P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * j + l15];      // A: row of X_j
+                        const double bv = P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];       // B: row of X_i
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15] = acc[reg];
+                    for (int reg = 0; reg < 4; ++reg) P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15] = acc[reg];
                 }
         }
         __syncthreads();
     }
-    // L goes to the lower triangle; the STRICT UPPER part of each diagonal 16x16 block (never read by a lower-triangular
-    // consumer) receives inv(L_qq) transposed, which k_trsm_64m picks up instead of inverting the blocks again
+}
+
+// L goes to the lower triangle of the 64x64 block at A; the STRICT UPPER part of each diagonal 16x16 block (never read by
+// a lower-triangular consumer) receives inv(L_qq) transposed, which the panel solves pick up instead of inverting again
+__device__ __forceinline__ void potf2b_store(double* __restrict__ A, int lda, int nb, const Potf2Lds& P, int tid, int nthreads) {
+    for (int idx = tid; idx < 4096; idx += nthreads) {
+        const int r = idx & 63, c = idx >> 6;
+        if (r < nb && c < nb) {
+            if (c <= r) A[(size_t)c * lda + r] = P.S[c * PB_LD + r];
+            else if ((c >> 4) == (r >> 4)) A[(size_t)c * lda + r] = P.Einv[c >> 4][c & 15][r & 15];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
+                                                    int goff, long long bstride, int istride, int xbar) {
+    A += (size_t)blockIdx.x * bstride;
+    info += (size_t)blockIdx.x * istride;
+    __shared__ Potf2Lds P;
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int idx = tid + 256 * k;
         const int r = idx & 63, c = idx >> 6;
-        if (r < nb && c < nb) {
-            if (c <= r) A[(size_t)c * lda + r] = S[c * PB_LD + r];
-            else if ((c >> 4) == (r >> 4)) A[(size_t)c * lda + r] = Einv[c >> 4][c & 15][r & 15];
-        }
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c <= r) v = A[(size_t)c * lda + r];
+        P.S[c * PB_LD + r] = v;
     }
+    __syncthreads();
+    potf2b_core(P, info, goff, xbar);
+    potf2b_store(A, lda, nb, P, tid, 256);
 }
 
 static int g_potf2_valu = -1;     // NMGP_POTF2=valu selects the unblocked kernel (k_potf2_64)
@@ -905,16 +886,15 @@ static thread_local int g_precise = 0;
 
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride) {
-    if (g_fuse.on && g_fuse.done_at == goff) return;      // already factored by the tile (0, 0) of the previous update
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
         g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
     }
     if (g_potf2_valu || g_precise)
-        hipLaunchKernelGGL(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
+        NMGP_LAUNCH(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
     else
-        hipLaunchKernelGGL(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride, g_potf2_xbar);
+        NMGP_LAUNCH(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride, g_potf2_xbar);
 }
 
 static int g_potf2_exports_inv() {
@@ -923,7 +903,7 @@ static int g_potf2_exports_inv() {
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
         g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
     }
-    return (g_potf2_valu || g_precise || g_fuse.on) ? 0 : 1;
+    return (g_potf2_valu || g_precise) ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1242,17 +1222,229 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
         g_trsm_slow = (e && std::strcmp(e, "staged") == 0) ? 1 : 0;
     }
     if (g_trsm_valu || g_precise) {
-        hipLaunchKernelGGL(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
+        NMGP_LAUNCH(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
     } else if (nb == 64 && g_potf2_exports_inv() && !g_trsm_slow) {
-        hipLaunchKernelGGL(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
+        NMGP_LAUNCH(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
     } else {
         // groups of 128 rows per workgroup: more of them amortise the factor preparation once the launch would fill the
         // chip (512 resident workgroups) several times over anyway
         const long long wgs = (long long)cdiv_c(rows, 128) * batch;
         const int reps = wgs >= 4096 ? 4 : (wgs >= 2048 ? 2 : 1);
-        hipLaunchKernelGGL(k_trsm_64m, dim3(cdiv_c(rows, 128 * reps), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride,
+        NMGP_LAUNCH(k_trsm_64m, dim3(cdiv_c(rows, 128 * reps), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride,
                            g_potf2_exports_inv(), reps);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused panel step: ONE launch per 64-column step of a panel instead of three dependent ones (diagonal block, panel solve,
+// K = 64 update).  A single matrix (or a handful of subjects) is latency-bound: 96 steps x (17 + 12 + 20 us) is the whole
+// evaluation time at n = 6144.  The dependency that forces three launches is that the update of step k must reach the next
+// diagonal block before it can be factored.  Here the update is DELAYED by one step and the next diagonal block is factored
+// by look-ahead inside the same launch:
+//
+//   state before step k (columns ck .. ck+63, ck = c0 + 64 k, panel = columns [c0, pend)):
+//     * columns < ck are final; the diagonal block (ck, ck) is factored, inverted 16x16 blocks in its upper part;
+//     * rows >= ck + 64 of the panel columns >= ck have received every column block < k - 1, but NOT block k - 1.
+//   step k, workgroups 0 .. T-1 ("solve" role, 8 waves x 16 rows each, rows >= ck + 64):
+//     1. catch-up: C[rows, block k] and C[rows, block k+1] -= X[rows, block k-1] L[.., block k-1]^T   (K = 64, MFMA; the
+//        operands are final since the previous launch, so no workgroup waits for another);
+//     2. solve: X[rows, block k] = C[rows, block k] inv(L_kk)^T  (the 16x16-blocked scheme of k_trsm_64f);
+//     3. workgroup 0 only -- it owns block row k+1: D = C[k+1, k+1] - X[k+1, k] X[k+1, k]^T, factor D (potf2b_core) and
+//        store it: the diagonal block of step k + 1 is ready when this launch ends;
+//   workgroups T .. ("update" role): the catch-up of the remaining panel columns >= ck + 128, rows >= ck + 128, with the
+//     same column block k - 1 -- ordinary k_syrk_lower tiles (syrk_tile_body) that fill the other CUs meanwhile.
+//   After the last step of the panel nothing is pending inside it: the trailing update applies all panel columns at once.
+// Critical path per step: one launch, two K = 64 MFMA passes over 64 rows, the 64x64 factorisation.
+// ---------------------------------------------------------------------------------------------
+#define PS_XLD 66
+#define PS_SMEM_DOUBLES (64 * PS_XLD + (int)(sizeof(Potf2Lds) / sizeof(double)))
+
+__global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
+                                                        int m_act, int pend, long long bstride, int* __restrict__ info,
+                                                        int istride, int T, int u_mrows, int u_ncols, int u_kflags,
+                                                        int u_tiles, int nbatch, int xbar) {
+    __shared__ __attribute__((aligned(32))) double smem[PS_SMEM_DOUBLES > 4 * SY_BK * SY_LD ? PS_SMEM_DOUBLES : 4 * SY_BK * SY_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if ((int)blockIdx.x >= T) {
+        // ---- update role: one 128x128 tile of the delayed K = 64 update of the remaining panel columns ----
+        const int t = (int)blockIdx.x - T + (int)blockIdx.y * u_tiles;       // compact tile index over the batch
+        const double* Ap = Ab + (size_t)(ck - 64) * lda + (ck + 128);
+        double* Cp = Ab + (size_t)(ck + 128) * lda + (ck + 128);
+        syrk_tile_body<4, SY_BK>(Ap, lda, Cp, lda, u_mrows, u_ncols, 64, bstride, bstride, u_kflags, -u_tiles, nbatch, t, 0,
+                                 0, smem, smem + 2 * SY_BK * SY_LD);
+        return;
+    }
+    // ---- solve role ----
+    double* A = Ab + (size_t)blockIdx.y * bstride;
+    v4d* opsC = reinterpret_cast<v4d*>(smem);                    // [4 q][4 sg][64 lanes]: -L[cb + 16 q + i][4 (4 sg + kk) + l4]
+    v4d* opsT = reinterpret_cast<v4d*>(smem + 4096);             // [10][64 lanes], as in k_trsm_64f
+    const bool special = (blockIdx.x == 0) && has_next;
+    const int row = ck + 64 + 128 * (int)blockIdx.x + 16 * w + l15;
+    const bool rv = row < m_act;
+    const int rowc = rv ? row : (m_act - 1);                      // clamped: loads stay in bounds, results are masked
+    // (1) issue every global load this thread needs up front
+    double oc[8], ot[5];
+    v4d Xp[4], Tk[4], Un[4];
+    const double* Lp = A + (size_t)(ck - 64) * lda;               // column block k - 1
+    if (has_prev) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
+            oc[j] = -Lp[(size_t)(4 * sx + (l >> 4)) * lda + ck + 16 * q + (l & 15)];
+        }
+    }
+    {
+        const double* L = A + (size_t)ck * lda + ck;              // diagonal block k (factor + inverted 16x16 blocks)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int idx = tid + 512 * j;                        // 0 .. 2559
+            const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+            const int rr = l & 15, kc = 4 * kk + (l >> 4);
+            double v;
+            if (blk < 6) {
+                const int q = blk == 0 ? 1 : (blk < 3 ? 2 : 3);
+                const int pp = blk == 0 ? 0 : (blk < 3 ? blk - 1 : blk - 3);
+                v = -L[(size_t)(16 * pp + kc) * lda + 16 * q + rr];
+            } else {
+                const int q = blk - 6;                   // inv(L_qq)[rr][kc] (kc < rr) sits at row 16 q + kc, column 16 q + rr
+                if (kc < rr) v = L[(size_t)(16 * q + rr) * lda + 16 * q + kc];
+                else if (kc == rr) v = 1.0 / L[(size_t)(16 * q + rr) * lda + 16 * q + rr];
+                else v = 0.0;
+            }
+            ot[j] = v;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * q + 4 * r + l4;
+            Tk[q][r] = rv ? A[(size_t)(ck + c) * lda + rowc] : 0.0;
+            Xp[q][r] = (rv && has_prev) ? Lp[(size_t)c * lda + rowc] : 0.0;
+            Un[q][r] = (rv && has_next) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
+        }
+    // (2) operands to LDS
+    if (has_prev) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
+            smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int idx = tid + 512 * j;
+        const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+        smem[4096 + (blk * 64 + l) * 4 + kk] = ot[j];
+    }
+    __syncthreads();
+    // operands of the second catch-up (column block k + 1) travel while the first one computes
+    if (has_prev && has_next) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
+            oc[j] = -Lp[(size_t)(4 * sx + (l >> 4)) * lda + ck + 64 + 16 * q + (l & 15)];
+        }
+    }
+    // (3) catch-up of column block k:  T_q -= X_prev L_prev[block k, q]^T
+    if (has_prev) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const v4d a = opsC[(q * 4 + sg) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Xp[sg][kk], Tk[q], 0, 0, 0);
+            }
+    }
+    // (4) solve against the diagonal block (right-looking over the four 16-column blocks, see k_trsm_64f)
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        const v4d ai = opsT[(6 + pp) * 64 + lane];
+        v4d x0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], Tk[pp][kk], x0, 0, 0, 0);
+        Tk[pp] = x0;
+#pragma unroll
+        for (int q = pp + 1; q < 4; ++q) {
+            const v4d a = opsT[((q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp) * 64 + lane];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Tk[pp][kk], Tk[q], 0, 0, 0);
+        }
+    }
+    if (rv) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(size_t)(ck + 16 * q + 4 * r + l4) * lda + row] = Tk[q][r];
+    }
+    if (!has_next) return;                                        // uniform: last step of the panel
+    // (5) catch-up of column block k + 1
+    if (has_prev) {
+        __syncthreads();                                          // every wave is done with the operands of block k
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
+            smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const v4d a = opsC[(q * 4 + sg) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Xp[sg][kk], Un[q], 0, 0, 0);
+            }
+    }
+    if (!special) {
+        if (rv) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(size_t)(ck + 64 + 16 * q + 4 * r + l4) * lda + row] = Un[q][r];
+        }
+        return;
+    }
+    // (6) look-ahead (workgroup 0): waves 0..3 hold block row k + 1 (rows ck+64 .. ck+127, always valid: has_next)
+    double* Xs = smem;                                            // [64 rows][PS_XLD]: X[k+1, k]
+    Potf2Lds& P = *reinterpret_cast<Potf2Lds*>(smem + 64 * PS_XLD);
+    __syncthreads();                                              // operands in LDS are dead from here on
+    if (w < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(16 * w + l15) * PS_XLD + 16 * q + 4 * r + l4] = Tk[q][r];
+    } else if (rv) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(size_t)(ck + 64 + 16 * q + 4 * r + l4) * lda + row] = Un[q][r];
+    }
+    __syncthreads();
+    if (w < 4) {
+        // D[own 16 rows, 16 q ..] = U_q - X[own rows] X[16 q + i]^T
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double a = -Xs[(16 * q + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
+                    Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tk[sg][kk], Un[q], 0, 0, 0);
+                }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * w + l15, cc = 16 * q + 4 * r + l4;
+                P.S[cc * PB_LD + rr] = (cc <= rr) ? Un[q][r] : 0.0;
+            }
+    }
+    __syncthreads();
+    potf2b_core(P, info + (size_t)blockIdx.y * istride, ck + 64, xbar);
+    potf2b_store(A + (size_t)(ck + 64) * lda + (ck + 64), lda, 64, P, tid, 512);
 }
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
@@ -1264,7 +1456,7 @@ __global__ void k_set_row(double* __restrict__ A, int lda, int row, const double
 }
 void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n, int batch, long long bstride,
              long long vstride) {
-    hipLaunchKernelGGL(k_set_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
+    NMGP_LAUNCH(k_set_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
 }
 __global__ void k_get_row(const double* __restrict__ A, int lda, int row, double* __restrict__ v, int n,
                           long long bstride, long long vstride) {
@@ -1273,7 +1465,7 @@ __global__ void k_get_row(const double* __restrict__ A, int lda, int row, double
 }
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
              long long vstride) {
-    hipLaunchKernelGGL(k_get_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
+    NMGP_LAUNCH(k_get_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
 }
 
 // rows that take part when the factorisation has reached column `cend`: the n matrix rows, the `extra` dense rows
@@ -1299,8 +1491,7 @@ static void factor_panel_rl(hipStream_t s, double* A, int lda, int n, int extra,
             trsm_64(s, Ajj, lda, jb, Apan, lda, below, batch, bs);
             const int ncols = c0 + w1 - (j0 + jb);
             if (ncols > 0)
-                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1,
-                           0, j0 + jb);
+                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1, 0);
         }
     }
 }
@@ -1320,9 +1511,34 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
     const int c1 = c0 + h;
     const int below = active_rows(n, extra, xtri, c1) - c1;
     if (below > 0)
-        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0, c1);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0);
     factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
 }
+
+// One fused launch per 64-column step (k_panel_step).  Needs full 64-column blocks and the blocked diagonal factorisation
+// (inverted 16x16 blocks in the factor).
+static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
+                               int batch, long long bs, int is) {
+    potf2_64(s, A + (size_t)c0 * lda + c0, lda, 64, info, c0, batch, bs, is);      // the panel's first diagonal block
+    const int nk = w / 64;
+    for (int k = 0; k < nk; ++k) {
+        const int ck = c0 + 64 * k;
+        const int m_act = active_rows(n, extra, xtri, ck + 64);
+        const int rows = m_act - (ck + 64);
+        if (rows <= 0) continue;                     // last block of the matrix and nothing below it
+        const int has_prev = k > 0, has_next = k + 1 < nk;
+        const int T = cdiv_c(rows, 128);
+        SyrkPlan pl;
+        const int u_m = m_act - (ck + 128), u_n = c0 + w - (ck + 128);
+        if (has_prev && u_m > 0 && u_n > 0) pl = syrk_plan(lda, lda, u_m, u_n, 64, 1, 0, true);
+        NMGP_LAUNCH(k_panel_step, dim3(T + pl.tiles, batch), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
+                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar);
+    }
+}
+
+// panel schedule: NMGP_CHOL_PANEL = fused | rec | rl | auto (default)
+static int g_panel_mode = -1;      // 0 auto, 1 fused, 2 rec, 3 rl
+static int g_fused_max_batch = 16; // NMGP_CHOL_FUSED_MAX_BATCH: largest batch that takes the fused steps under auto
 
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
@@ -1330,10 +1546,18 @@ static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, in
         const char* e = std::getenv("NMGP_CHOL_REC_MIN_BATCH");
         return e ? std::atoi(e) : 4;
     }();
-    if (batch >= rec_min_batch)
-        factor_panel_rec(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
-    else
+    if (g_panel_mode < 0) {
+        const char* e = std::getenv("NMGP_CHOL_PANEL");
+        g_panel_mode = !e ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : (std::strcmp(e, "rec") == 0 ? 2 : (std::strcmp(e, "rl") == 0 ? 3 : 0)));
+        if (const char* m = std::getenv("NMGP_CHOL_FUSED_MAX_BATCH")) g_fused_max_batch = std::atoi(m);
+    }
+    const bool can_fuse = (w % 64 == 0) && g_potf2_exports_inv() && (lda % 2 == 0);
+    if (can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && batch <= g_fused_max_batch)))
+        factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+    else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+    else
+        factor_panel_rec(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
 }
 
 // Blocked Cholesky of the n x n lower triangle of A.  Below the matrix the same array may hold
@@ -1369,23 +1593,6 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     const int is = istride;
     const long long bs = bstride;
     const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
-    // NMGP_FUSE_POTF2=1: factor the next diagonal block inside the preceding update's tile (0, 0).  Off by default: next
-    // to MFMA-saturated tiles the VALU-bound block factorisation runs ~3.5x slower (90 us), which the many short
-    // panel-internal launches cannot hide (measured 602 vs 634 evals/s at 32 chains, 137 vs 143 for one chain).
-    static const bool fuse_env = [] {
-        const char* e = std::getenv("NMGP_FUSE_POTF2");
-        return e && std::atoi(e) != 0;
-    }();
-    struct FuseScope {
-        PotfFuse prev;
-        FuseScope() : prev(g_fuse) {}
-        ~FuseScope() { g_fuse = prev; }
-    } fs;
-    g_fuse.on = fuse_env && !la;
-    g_fuse.info = info;
-    g_fuse.istride = is;
-    g_fuse.n = n;
-    g_fuse.done_at = -1;
     if (!la) {
         for (int c0 = 0; c0 < n; c0 += nb1) {
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
@@ -1393,7 +1600,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
             const int c1 = c0 + w1;
             if (c1 < n)
                 syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda,
-                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0, c1);
+                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0);
         }
         return;
     }
@@ -1438,7 +1645,7 @@ __global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ A, i
     if (r < n + pad) A[(size_t)blockIdx.z * bstride + (size_t)c * lda + row0 + r] = (r - pad == c) ? 1.0 : 0.0;
 }
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch, long long bstride) {
-    hipLaunchKernelGGL(k_identity_rows, dim3(cdiv_c(n + pad, 256), n, batch), dim3(256), 0, s, A, lda, row0, n, pad,
+    NMGP_LAUNCH(k_identity_rows, dim3(cdiv_c(n + pad, 256), n, batch), dim3(256), 0, s, A, lda, row0, n, pad,
                        bstride);
 }
 

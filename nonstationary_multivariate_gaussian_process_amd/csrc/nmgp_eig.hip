@@ -386,6 +386,41 @@ int kron_chol_adjoint(nmgp_ctx* c, EigWork& w, CholKron& ck, const double* d_ell
     return 0;
 }
 
+// The reference never lets a NaN likelihood out of the separable / stationary objectives: `while loglik != loglik:
+// loglik = multivariate_normal_logpdf1(...)` (logpos.py:267-268, 436-437) retries with `precision`-sized RANDOM jitter on the
+// diagonals of B and K (distributions.py:66,69).  The same safety net, made deterministic: after a numerical failure
+// (a block that is not positive definite, a non-finite likelihood, the eigensolver) the evaluation is repeated up to
+// NMGP_SEP_RETRIES times with attempt * precision added to both diagonals; value and gradient then belong to that slightly
+// regularised covariance, like the reference's.  Only if every attempt fails does the failure reach the caller.
+#define NMGP_SEP_RETRIES 3
+template <class BuildK>
+int kron_likelihood_with_retry(nmgp_ctx* c, EigWork& w, int M, int N, double sigma2, bool want_grad, BuildK&& build_K,
+                               double hs[4], double* loglik, CholKron* ck, int* attempts) {
+    const std::vector<double> B0 = w.h_B;
+    int rc = 0;
+    for (int attempt = 0; attempt <= NMGP_SEP_RETRIES; ++attempt) {
+        const double jit = attempt * NMGP_PRECISION;
+        w.h_B = B0;
+        for (int i = 0; i < M; ++i) w.h_B[(size_t)i * M + i] += jit;
+        jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
+        NMGP_TRY(setup_small(c, w, M, N, sigma2));
+        build_K();
+        if (attempt > 0) add_diag(c->stream, c->d_K, N, N, jit);
+        *loglik = std::nan("");
+        if (c->sep_algo == 1)
+            rc = kron_chol_loglik(c, w, sigma2, want_grad, loglik, ck);
+        else
+            rc = kron_loglik(c, w, c->d_y, sigma2, want_grad, hs, loglik);
+        if (rc < 0) return rc;                                    // API / runtime error: not a numerical matter
+        if (rc == 0 && std::isfinite(*loglik)) {
+            *attempts = attempt;
+            return 0;
+        }
+    }
+    *attempts = NMGP_SEP_RETRIES;
+    return rc;      // > 0: the last numerical failure; 0 with a non-finite loglik is reported by the caller
+}
+
 int require_data(nmgp_ctx* c) {
     if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called before evaluating");
     return 0;
@@ -413,20 +448,18 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
     HIP_TRY(c, hipMemcpyAsync(c->d_pars, pars, P * sizeof(double), hipMemcpyHostToDevice, s));
     EigWork w;
     build_B(pars + 2 * N, M, true, w.h_L, w.h_B);
-    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
-    NMGP_TRY(setup_small(c, w, M, N, sigma2));
     {
         NmgpStage sp(c, NMGP_STAGE_COV);
         exp_vec(s, c->d_pars, N, c->d_ell);
         exp_vec(s, c->d_pars + N, N, c->d_sig);
-        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
     }
     double hs[4], loglik;
     CholKron ck;
-    if (c->sep_algo == 1)
-        NMGP_TRY(kron_chol_loglik(c, w, sigma2, grad != nullptr, &loglik, &ck));
-    else
-        NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    int attempts = 0;
+    NMGP_TRY(kron_likelihood_with_retry(c, w, M, N, sigma2, grad != nullptr, [&] {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
+    }, hs, &loglik, &ck, &attempts));
     // GP priors on tilde_l and tilde_sigma (logpos.py:271-281)
     PriorFactor *pl = nullptr, *ps = nullptr;
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
@@ -480,6 +513,7 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         if (prior) ge += (-a - 1.0) + b / sigma2 + 1.0;
         grad[P - 1] = -ge;
     }
+    NMGP_TRY(nmgp_take_launch_error(c));
     if (!std::isfinite(out6[1])) return nmgp_fail(c, NMGP_NUM_NAN, "non-finite separable likelihood (%g)", out6[1]);
     return 0;
 }
@@ -502,8 +536,6 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
     NMGP_TRY(ensure_eig_buffers(c, N));
     EigWork w;
     build_B(pars + 2, M, true, w.h_L, w.h_B);
-    jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
-    NMGP_TRY(setup_small(c, w, M, N, sigma2));
     {
         NmgpStage sp(c, NMGP_STAGE_COV);
         // l = exp(tilde_l * ones(N)), sigma = exp(tilde_sigma * ones(N))  (logpos.py:424-425)
@@ -511,14 +543,14 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
         fill_vec(s, c->d_R + N, N, ts);
         exp_vec(s, c->d_R, N, c->d_ell);
         exp_vec(s, c->d_R + N, N, c->d_sig);
-        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:429
     }
     double hs[4], loglik;
     CholKron ck;
-    if (c->sep_algo == 1)
-        NMGP_TRY(kron_chol_loglik(c, w, sigma2, grad != nullptr, &loglik, &ck));
-    else
-        NMGP_TRY(kron_loglik(c, w, c->d_y, sigma2, grad != nullptr, hs, &loglik));
+    int attempts = 0;
+    NMGP_TRY(kron_likelihood_with_retry(c, w, M, N, sigma2, grad != nullptr, [&] {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:429
+    }, hs, &loglik, &ck, &attempts));
     double dl = 0.0, lp_l = 0.0, lp_uL = 0.0, lp_s2 = 0.0;
     std::vector<double> g_uL_prior(T, 0.0);
     // the reference only evaluates the prior terms when Prior is true (logpos.py:445-458)
@@ -552,6 +584,7 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
         if (prior) ge += (-a - 1.0) + b / sigma2 + 1.0;
         grad[P - 1] = -ge;
     }
+    NMGP_TRY(nmgp_take_launch_error(c));
     if (!std::isfinite(out5[1])) return nmgp_fail(c, NMGP_NUM_NAN, "non-finite stationary likelihood (%g)", out5[1]);
     return 0;
 }

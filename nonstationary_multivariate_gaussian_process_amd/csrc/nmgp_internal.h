@@ -165,6 +165,19 @@ struct NmgpStage {   // RAII HIP-event timer of one stage on the context's strea
                              __FILE__, __LINE__);                                                 \
     } while (0)
 
+// Kernel launches go through NMGP_LAUNCH: a launch the runtime rejects (block size, LDS or grid limits) would otherwise be
+// silent -- the next fetch would copy stale results and return 0.  The failure is recorded with the kernel's name
+// (thread-local: a context belongs to one host thread) and turned into NMGP_E_HIP by nmgp_take_launch_error() at the next
+// API boundary.
+void nmgp_note_launch_error(const char* kernel, hipError_t e);
+int nmgp_take_launch_error(nmgp_ctx* c);
+#define NMGP_LAUNCH(kern, ...)                                             \
+    do {                                                                   \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                             \
+        hipError_t le__ = hipGetLastError();                               \
+        if (le__ != hipSuccess) nmgp_note_launch_error(#kern, le__);       \
+    } while (0)
+
 #define NMGP_TRY(expr)          \
     do {                        \
         int r__ = (expr);       \
@@ -260,7 +273,7 @@ int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double*
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride = -1, int ktri = 0, int next_c = -1);
+                long long bstride, long long cstride = -1, int ktri = 0);
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch = 1, long long bstride = 0);
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride);

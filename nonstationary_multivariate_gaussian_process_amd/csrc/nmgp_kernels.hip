@@ -53,7 +53,7 @@ __global__ void k_svc_prep(const double* __restrict__ pars, int N, int M, int T,
 
 void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv, int batch) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_prep, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, M, T, ell, Lv);
+    NMGP_LAUNCH(k_svc_prep, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, M, T, ell, Lv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,9 +139,9 @@ static void launch_svc_cov(hipStream_t s, const double* x, const double* ell, co
                            double* S, int ld, int N, bool full, int batch, long long sstride, int xstride) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
-        hipLaunchKernelGGL((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
+        NMGP_LAUNCH((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
     else
-        hipLaunchKernelGGL((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
+        NMGP_LAUNCH((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
 }
 
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse, double* S,
@@ -214,18 +214,18 @@ void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double bet
                  int batch) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
-        hipLaunchKernelGGL((k_cov_sym<false, true>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
+        NMGP_LAUNCH((k_cov_sym<false, true>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
     else
-        hipLaunchKernelGGL((k_cov_sym<false, false>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
+        NMGP_LAUNCH((k_cov_sym<false, false>), grid, dim3(256), 0, s, x, nullptr, nullptr, N, alpha, beta, out, ld);
 }
 
 void gibbs_cov_sym(hipStream_t s, const double* x, const double* sig, const double* ell, int N, double* out, int ld,
                    bool full) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64));
     if (full)
-        hipLaunchKernelGGL((k_cov_sym<true, true>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
+        NMGP_LAUNCH((k_cov_sym<true, true>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
     else
-        hipLaunchKernelGGL((k_cov_sym<true, false>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
+        NMGP_LAUNCH((k_cov_sym<true, false>), grid, dim3(256), 0, s, x, sig, ell, N, 1.0, 1.0, out, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(256) void k_rect(const double* __restrict__ x1, con
 }
 
 void pairwise_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double* out) {
-    hipLaunchKernelGGL((k_rect<0>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
+    NMGP_LAUNCH((k_rect<0>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
                        nullptr, nullptr, n2, d, 1.0, 1.0, 0, out);
 }
 void rbf_cov_rect(hipStream_t s, const double* x1, int n1, const double* x2, int n2, int d, double alpha, double beta,
                   bool sym, double* out) {
-    hipLaunchKernelGGL((k_rect<1>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
+    NMGP_LAUNCH((k_rect<1>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, nullptr, nullptr, n1, x2,
                        nullptr, nullptr, n2, d, alpha, beta, sym ? 1 : 0, out);
 }
 void gibbs_cov_rect(hipStream_t s, const double* x1, const double* s1, const double* l1, int n1, const double* x2,
                     const double* s2, const double* l2, int n2, int d, bool sym, double* out) {
-    hipLaunchKernelGGL((k_rect<2>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, s1, l1, n1, x2, s2, l2, n2,
+    NMGP_LAUNCH((k_rect<2>), dim3(cdiv(n2, 64), cdiv(n1, 4)), dim3(256), 0, s, x1, s1, l1, n1, x2, s2, l2, n2,
                        d, 1.0, 1.0, sym ? 1 : 0, out);
 }
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_kron(const double* __restrict__ a, int 
 void kron_product(hipStream_t s, const double* a, int ar, int ac, const double* b, int br, int bc, double* out) {
     size_t W = (size_t)ac * bc, H = (size_t)ar * br;
     int gy = (int)(H < 4096 ? H : 4096);
-    hipLaunchKernelGGL(k_kron, dim3(cdiv(W, 256), gy), dim3(256), 0, s, a, ar, ac, b, br, bc, out);
+    NMGP_LAUNCH(k_kron, dim3(cdiv(W, 256), gy), dim3(256), 0, s, a, ar, ac, b, br, bc, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,12 +332,12 @@ __global__ __launch_bounds__(1024) void k_logdet_quad(const double* __restrict__
 
 void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const double* z, double* out_logdet,
                       double* out_quad, int batch, long long bstride, int ostride) {
-    hipLaunchKernelGGL(k_logdet_quad, dim3(batch), dim3(1024), 0, s, L, ld, n, z, out_logdet, out_quad, bstride,
+    NMGP_LAUNCH(k_logdet_quad, dim3(batch), dim3(1024), 0, s, L, ld, n, z, out_logdet, out_quad, bstride,
                        ostride);
 }
 
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out) {
-    hipLaunchKernelGGL(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, (const double*)nullptr, out,
+    NMGP_LAUNCH(k_logdet_quad, dim3(1), dim3(1024), 0, s, L, ld, n, (const double*)nullptr, out,
                        (double*)nullptr, 0LL, 0);
 }
 
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_col_sumsq(const double* __restrict__ R,
 }
 
 void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out) {
-    hipLaunchKernelGGL(k_col_sumsq, dim3(cols), dim3(256), 0, s, R, ld, rows, out);
+    NMGP_LAUNCH(k_col_sumsq, dim3(cols), dim3(256), 0, s, R, ld, rows, out);
 }
 
 // mirror the lower triangle into the upper one (column-major n x n)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld
 }
 
 void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch) {
-    hipLaunchKernelGGL(k_sym_fill, dim3(cdiv(n, 64), cdiv(n, 64), batch), dim3(256), 0, s, A, ld, n);
+    NMGP_LAUNCH(k_sym_fill, dim3(cdiv(n, 64), cdiv(n, 64), batch), dim3(256), 0, s, A, ld, n);
 }
 
 // y[m N + i] = Y[i, m]  (logpos.py:338)
@@ -389,7 +389,7 @@ __global__ void k_transpose_y(const double* __restrict__ Y, int N, int M, double
 }
 
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y) {
-    hipLaunchKernelGGL(k_transpose_y, dim3(cdiv((long long)N * M, 256)), dim3(256), 0, s, Y, N, M, y);
+    NMGP_LAUNCH(k_transpose_y, dim3(cdiv((long long)N * M, 256)), dim3(256), 0, s, Y, N, M, y);
 }
 
 // prior right-hand sides: column 0 = tilde_l - mu_l, column 1+t = uL[:, t] - mu_L (logpos.py:358,363-365)
@@ -406,7 +406,7 @@ __global__ void k_svc_prior_rhs(const double* __restrict__ pars, int N, int T, d
 
 void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
                    int batch) {
-    hipLaunchKernelGGL(k_svc_prior_rhs, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
+    NMGP_LAUNCH(k_svc_prior_rhs, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
 }
 
 // HBM stream micro-benchmark (16 B per lane)
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__
 }
 
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem) {
-    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, s, (const double2*)src, (double2*)dst, nelem / 2);
+    NMGP_LAUNCH(k_stream_copy, dim3(256 * 8), dim3(256), 0, s, (const double2*)src, (double2*)dst, nelem / 2);
 }
 
 
@@ -532,7 +532,7 @@ int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double*
                 const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch, int xstride) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);      // batched: Sinv matrices are ld x (N M) apart (ld == N M there)
 #define NMGP_ADJ(MM) \
-    hipLaunchKernelGGL((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign, xstride)
+    NMGP_LAUNCH((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign, xstride)
     switch (M) {
         case 1: NMGP_ADJ(1); break;
         case 2: NMGP_ADJ(2); break;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(1024) void k_trace_terms(const double* __restrict__
 
 void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out, double ssign,
                  int batch) {
-    hipLaunchKernelGGL(k_trace_terms, dim3(batch), dim3(1024), 0, s, alpha, Sinv, ld, n, out, ssign);
+    NMGP_LAUNCH(k_trace_terms, dim3(batch), dim3(1024), 0, s, alpha, Sinv, ld, n, out, ssign);
 }
 
 // Assemble d NegLog / d pars from the adjoint partials, the prior solves and the scalar terms.
@@ -625,7 +625,7 @@ void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, con
                     int ldR, const double* pars, const double* tr, double a, double b, int prior, double* grad,
                     int batch) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_grad_final, dim3(cdiv(N, 256), batch), dim3(256), 0, s, part, NJ, N, M, T, Lv, R2, ldR,
+    NMGP_LAUNCH(k_svc_grad_final, dim3(cdiv(N, 256), batch), dim3(256), 0, s, part, NJ, N, M, T, Lv, R2, ldR,
                        pars, tr, a, b, prior, grad);
 }
 
@@ -672,7 +672,7 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
                   double ig_const, int prior, double* out5, int batch, int sstride, int hstride) {
-    hipLaunchKernelGGL(k_svc_finalize, dim3(batch), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
+    NMGP_LAUNCH(k_svc_finalize, dim3(batch), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
                        ig_const, prior, out5, sstride, hstride);
 }
 
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(1024) void k_half_logdet(const double* __restrict__
 }
 
 void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int batch) {
-    hipLaunchKernelGGL(k_half_logdet, dim3(batch), dim3(1024), 0, s, L, ld, n, out);
+    NMGP_LAUNCH(k_half_logdet, dim3(batch), dim3(1024), 0, s, L, ld, n, out);
 }
 
 
@@ -780,9 +780,9 @@ void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long 
                 double* R, int N, int nrhs, int batch) {
     const size_t lds = ((size_t)N + 64 * 65 + 64) * sizeof(double);
     if (trans)
-        hipLaunchKernelGGL(k_prior_trsv<true>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
     else
-        hipLaunchKernelGGL(k_prior_trsv<false>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<false>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
 }
 
 }  // namespace nmgpk

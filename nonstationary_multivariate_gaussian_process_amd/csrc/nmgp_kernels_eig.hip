@@ -106,9 +106,9 @@ int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, con
     if (m2 > 64) return NMGP_E_UNSUPPORTED;
     const bool vec2 = (n2 % 2 == 0) && (((size_t)K | (size_t)y) % 16 == 0);
     if (vec2)
-        hipLaunchKernelGGL((k_kron_mv<true>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
+        NMGP_LAUNCH((k_kron_mv<true>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
     else
-        hipLaunchKernelGGL((k_kron_mv<false>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
+        NMGP_LAUNCH((k_kron_mv<false>), dim3(cdiv(n1, 4)), dim3(256), 0, s, K, n1, n2, y, B, m1, m2, out);
     return 0;
 }
 
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_eig_reduce(double* __restrict__ a, con
 
 void eig_reduce(hipStream_t s, double* a, const double* wB, int M, const double* wK, int N, const double* sigma2p,
                 bool scale, double* out) {
-    hipLaunchKernelGGL(k_eig_reduce, dim3(1), dim3(1024), 0, s, a, wB, M, wK, N, sigma2p, scale ? 1 : 0, out);
+    NMGP_LAUNCH(k_eig_reduce, dim3(1), dim3(1024), 0, s, a, wB, M, wK, N, sigma2p, scale ? 1 : 0, out);
 }
 
 // dvec[q] = sum_p wB[p] / (sigma2 + wB[p] wK[q]);  Vs[:, q] = V[:, q] * dvec[q]   (column-major N x N)
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_colscale_d(const double* __restrict__ V
 
 void colscale_d(hipStream_t s, const double* V, const double* wB, int M, const double* wK, int N, const double* sigma2p,
                 double* Vs) {
-    hipLaunchKernelGGL(k_colscale_d, dim3(cdiv(N, 256), N), dim3(256), 0, s, V, wB, M, wK, N, sigma2p, Vs);
+    NMGP_LAUNCH(k_colscale_d, dim3(cdiv(N, 256), N), dim3(256), 0, s, V, wB, M, wK, N, sigma2p, Vs);
 }
 
 // Vs[:, q] = V[:, q] * svec[q]
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_colscale(const double* __restrict__ V, 
 }
 
 void colscale(hipStream_t s, const double* V, const double* svec, int rows, int cols, double* Vs) {
-    hipLaunchKernelGGL(k_colscale, dim3(cdiv(rows, 256), cols), dim3(256), 0, s, V, svec, rows, cols, Vs);
+    NMGP_LAUNCH(k_colscale, dim3(cdiv(rows, 256), cols), dim3(256), 0, s, V, svec, rows, cols, Vs);
 }
 
 // coreB[p, p'] = sum_q wK[q] At[p,q] At[p',q]  - d_pp' sum_q wK[q] / (sigma2 + wB[p] wK[q])      (M x M, one block)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_sep_coreB(const double* __restrict__ At
 
 void sep_coreB(hipStream_t s, const double* At, const double* wB, int M, const double* wK, int N,
                const double* sigma2p, double* coreB) {
-    hipLaunchKernelGGL(k_sep_coreB, dim3(M * M), dim3(256), 0, s, At, wB, M, wK, N, sigma2p, coreB);
+    NMGP_LAUNCH(k_sep_coreB, dim3(M * M), dim3(256), 0, s, At, wB, M, wK, N, sigma2p, coreB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_sep_adjoint(const double* __restrict__ 
 
 void sep_adjoint(hipStream_t s, const double* x, const double* ell, const double* sig, const double* U,
                  const double* wB, int M, const double* C, int N, double* part) {
-    hipLaunchKernelGGL(k_sep_adjoint, dim3(cdiv(N, 64), cdiv(N, 64)), dim3(256), 0, s, x, ell, sig, U, wB, M, C, N, part);
+    NMGP_LAUNCH(k_sep_adjoint, dim3(cdiv(N, 64), cdiv(N, 64)), dim3(256), 0, s, x, ell, sig, U, wB, M, C, N, part);
 }
 
 // sum the J partials: g[i*2 + t]
@@ -297,7 +297,7 @@ __global__ void k_sep_grad_sum(const double* __restrict__ part, int NJ, int N, d
 }
 
 void sep_grad_sum(hipStream_t s, const double* part, int NJ, int N, double* g) {
-    hipLaunchKernelGGL(k_sep_grad_sum, dim3(cdiv(N, 256)), dim3(256), 0, s, part, NJ, N, g);
+    NMGP_LAUNCH(k_sep_grad_sum, dim3(cdiv(N, 256)), dim3(256), 0, s, part, NJ, N, g);
 }
 
 // elementwise helpers -----------------------------------------------------------------------------
@@ -306,7 +306,7 @@ __global__ void k_exp_vec(const double* __restrict__ in, int n, double* __restri
     if (i < n) out[i] = exp(in[i]);
 }
 void exp_vec(hipStream_t s, const double* in, int n, double* out) {
-    hipLaunchKernelGGL(k_exp_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, in, n, out);
+    NMGP_LAUNCH(k_exp_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, in, n, out);
 }
 
 __global__ void k_fill_vec(double* __restrict__ out, int n, double v) {
@@ -314,7 +314,7 @@ __global__ void k_fill_vec(double* __restrict__ out, int n, double v) {
     if (i < n) out[i] = v;
 }
 void fill_vec(hipStream_t s, double* out, int n, double v) {
-    hipLaunchKernelGGL(k_fill_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, out, n, v);
+    NMGP_LAUNCH(k_fill_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, out, n, v);
 }
 
 // R[:, 0] = a - mu_a, R[:, 1] = b - mu_b
@@ -326,7 +326,7 @@ __global__ void k_two_col_rhs(const double* __restrict__ a, double mu_a, const d
     R[N + i] = b[i] - mu_b;
 }
 void two_col_rhs(hipStream_t s, const double* a, double mu_a, const double* b, double mu_b, int N, double* R) {
-    hipLaunchKernelGGL(k_two_col_rhs, dim3(cdiv(N, 256)), dim3(256), 0, s, a, mu_a, b, mu_b, N, R);
+    NMGP_LAUNCH(k_two_col_rhs, dim3(cdiv(N, 256)), dim3(256), 0, s, a, mu_a, b, mu_b, N, R);
 }
 
 // y - mu (mu may be null)
@@ -335,7 +335,7 @@ __global__ void k_sub_vec(const double* __restrict__ y, const double* __restrict
     if (i < n) out[i] = mu ? (y[i] - mu[i]) : y[i];
 }
 void sub_vec(hipStream_t s, const double* y, const double* mu, int n, double* out) {
-    hipLaunchKernelGGL(k_sub_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, y, mu, n, out);
+    NMGP_LAUNCH(k_sub_vec, dim3(cdiv(n, 256)), dim3(256), 0, s, y, mu, n, out);
 }
 
 // out[0] = sum_i a[i] b[i]
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_dot(const double* __restrict__ a, cons
     if (threadIdx.x == 0) out[0] = acc;
 }
 void dot(hipStream_t s, const double* a, const double* b, int n, double* out) {
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(1024), 0, s, a, b, n, out);
+    NMGP_LAUNCH(k_dot, dim3(1), dim3(1024), 0, s, a, b, n, out);
 }
 
 // U[(m*N+i), (p*N+q)] = VB[m,p] * VK[i,q], row-major [MN, MN]; VB row-major [M,M]; VK column-major (V[i + q*N])
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_kron_eigvec(const double* __restrict__ 
 }
 void kron_eigvec(hipStream_t s, const double* VB, int M, const double* VK, int N, double* U) {
     size_t n = (size_t)M * N;
-    hipLaunchKernelGGL(k_kron_eigvec, dim3(cdiv(n, 256), (unsigned)n), dim3(256), 0, s, VB, M, VK, N, U);
+    NMGP_LAUNCH(k_kron_eigvec, dim3(cdiv(n, 256), (unsigned)n), dim3(256), 0, s, VB, M, VK, N, U);
 }
 
 // tvec[p*N+q] = 1 / (sigma2 + wB[p] wK[q])
@@ -376,7 +376,7 @@ __global__ void k_kron_w(const double* __restrict__ wB, int M, const double* __r
     w[k] = 1.0 / (wB[k / N] * wK[k % N] + sigma2);
 }
 void kron_w(hipStream_t s, const double* wB, int M, const double* wK, int N, double sigma2, double* w) {
-    hipLaunchKernelGGL(k_kron_w, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, s, wB, M, wK, N, sigma2, w);
+    NMGP_LAUNCH(k_kron_w, dim3(cdiv((long long)M * N, 256)), dim3(256), 0, s, wB, M, wK, N, sigma2, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_svc_crosscov(const double* __restrict__
 void svc_crosscov(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M,
                   const double* xs, const double* tl_star, const double* Lstar, int S, double* KF) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_crosscov, dim3(cdiv(N, 256), S), dim3(256), 0, st, x, ell, Lv, N, M, T, xs, tl_star, Lstar,
+    NMGP_LAUNCH(k_svc_crosscov, dim3(cdiv(N, 256), S), dim3(256), 0, st, x, ell, Lv, N, M, T, xs, tl_star, Lstar,
                        S, KF);
 }
 
@@ -432,7 +432,7 @@ __global__ void k_svc_star(const double* __restrict__ proj, int S, int M, int T,
 void svc_star(hipStream_t st, const double* proj, int S, int M, double mu_l, double mu_L, double* tl_star,
               double* Lstar) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_star, dim3(cdiv(S, 256)), dim3(256), 0, st, proj, S, M, T, mu_l, mu_L, tl_star, Lstar);
+    NMGP_LAUNCH(k_svc_star, dim3(cdiv(S, 256)), dim3(256), 0, st, proj, S, M, T, mu_l, mu_L, tl_star, Lstar);
 }
 
 // var[s, m'] = kss (Lstar Lstar^T)[m', m'] - colsq[s M + m'] + sigma2, clipped (prediction.py:975-983)
@@ -454,7 +454,7 @@ __global__ void k_svc_predvar(const double* __restrict__ Lstar, const double* __
 void svc_predvar(hipStream_t st, const double* Lstar, const double* colsq, int S, int M, const double* tse,
                  double* var) {
     int T = M * (M + 1) / 2;
-    hipLaunchKernelGGL(k_svc_predvar, dim3(cdiv((long long)S * M, 256)), dim3(256), 0, st, Lstar, colsq, S, M, T, tse,
+    NMGP_LAUNCH(k_svc_predvar, dim3(cdiv((long long)S * M, 256)), dim3(256), 0, st, Lstar, colsq, S, M, T, tse,
                        var);
 }
 
@@ -490,9 +490,9 @@ void sep_crossvec(hipStream_t st, int mode, const double* x, const double* sig, 
                   double* KX) {
     dim3 grid(cdiv(N, 256), S);
     if (mode == 0)
-        hipLaunchKernelGGL((k_sep_crossvec<0>), grid, dim3(256), 0, st, x, sig, ell, N, xs, tl_star, ts_star, sig0, l0, S, KX);
+        NMGP_LAUNCH((k_sep_crossvec<0>), grid, dim3(256), 0, st, x, sig, ell, N, xs, tl_star, ts_star, sig0, l0, S, KX);
     else
-        hipLaunchKernelGGL((k_sep_crossvec<1>), grid, dim3(256), 0, st, x, sig, ell, N, xs, tl_star, ts_star, sig0, l0, S, KX);
+        NMGP_LAUNCH((k_sep_crossvec<1>), grid, dim3(256), 0, st, x, sig, ell, N, xs, tl_star, ts_star, sig0, l0, S, KX);
 }
 
 // Separable/stationary predictive moments in the joint eigenbasis (prediction.py:385-401):
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_sep_predict(const double* __restrict__ 
 void sep_predict(hipStream_t st, const double* Cq, const double* a, const double* wB, const double* VB, int M,
                  const double* wK, int N, double sigma2, const double* Bdiag, const double* kss, bool strict_clip, int S,
                  double* mean, double* var) {
-    hipLaunchKernelGGL(k_sep_predict, dim3(S * M), dim3(256), 0, st, Cq, a, wB, VB, M, wK, N, sigma2, Bdiag, kss,
+    NMGP_LAUNCH(k_sep_predict, dim3(S * M), dim3(256), 0, st, Cq, a, wB, VB, M, wK, N, sigma2, Bdiag, kss,
                        strict_clip ? 1 : 0, mean, var);
 }
 
@@ -548,7 +548,7 @@ __global__ void k_sep_star(const double* __restrict__ proj, int S, double mu_l, 
 }
 void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_s, double* tl_star, double* ts_star,
               double* kss) {
-    hipLaunchKernelGGL(k_sep_star, dim3(cdiv(S, 256)), dim3(256), 0, st, proj, S, mu_l, mu_s, tl_star, ts_star, kss);
+    NMGP_LAUNCH(k_sep_star, dim3(cdiv(S, 256)), dim3(256), 0, st, proj, S, mu_l, mu_s, tl_star, ts_star, kss);
 }
 
 
@@ -568,7 +568,7 @@ __global__ void k_rotate_y(const double* __restrict__ Y, const double* __restric
     yt[(size_t)p * N + i] = s;
 }
 void rotate_y(hipStream_t s, const double* Y, const double* VB, int N, int M, double* yt) {
-    hipLaunchKernelGGL(k_rotate_y, dim3(cdiv(N, 256), M), dim3(256), 0, s, Y, VB, N, M, yt);
+    NMGP_LAUNCH(k_rotate_y, dim3(cdiv(N, 256), M), dim3(256), 0, s, Y, VB, N, M, yt);
 }
 
 // out_p[i, j] = wB[p] K[i, j] + sigma2 d_ij   (lower triangle, column-major; K: ld = N, out: leading dimension ldo)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_sep_blocks(const double* __restrict__ K
 }
 void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* sigma2p, int N, int M, double* out,
                 int ldo, long long bstride) {
-    hipLaunchKernelGGL(k_sep_blocks, dim3(cdiv(N, 256), N, M), dim3(256), 0, s, K, wB, sigma2p, N, out, ldo, bstride);
+    NMGP_LAUNCH(k_sep_blocks, dim3(cdiv(N, 256), N, M), dim3(256), 0, s, K, wB, sigma2p, N, out, ldo, bstride);
 }
 
 // per block p (Cneg_p = -S_p^-1, lower, ld = N) partial sums over the columns j = blockIdx.y, +gridDim.y, ...:
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void k_sep_traces(const double* __restrict__ C
     }
 }
 int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double* alpha, int N, int M, double* out) {
-    hipLaunchKernelGGL(k_sep_traces, dim3(M, SEP_TR_G), dim3(256), 0, s, Cneg, K, alpha, N, out);
+    NMGP_LAUNCH(k_sep_traces, dim3(M, SEP_TR_G), dim3(256), 0, s, Cneg, K, alpha, N, out);
     return SEP_TR_G;
 }
 
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_weighted_sum_lower(const double* __rest
     C[(size_t)j * N + i] = -s;
 }
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C) {
-    hipLaunchKernelGGL(k_weighted_sum_lower, dim3(cdiv(N, 256), N), dim3(256), 0, s, Cneg, wB, N, M, C);
+    NMGP_LAUNCH(k_weighted_sum_lower, dim3(cdiv(N, 256), N), dim3(256), 0, s, Cneg, wB, N, M, C);
 }
 
 // A[r, r] += v  (n x n, leading dimension ld)
@@ -649,7 +649,7 @@ __global__ void k_add_diag(double* __restrict__ A, int ld, int n, double v) {
     if (r < n) A[(size_t)r * ld + r] += v;
 }
 void add_diag(hipStream_t s, double* A, int ld, int n, double v) {
-    hipLaunchKernelGGL(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, s, A, ld, n, v);
+    NMGP_LAUNCH(k_add_diag, dim3(cdiv(n, 256)), dim3(256), 0, s, A, ld, n, v);
 }
 
 }  // namespace nmgpk
