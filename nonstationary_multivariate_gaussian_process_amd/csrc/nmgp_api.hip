@@ -215,22 +215,40 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
         if (v >= 64) c->chol_nb1 = (v / 64) * 64;
     }
     HIP_TRY(c, hipSetDevice(device));
-    if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);
+    if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);   // default 1: see potrf_lower
     if (const char* e = std::getenv("NMGP_PRIOR_SOLVE")) c->prior_rocblas = std::strcmp(e, "rocblas") == 0;
     if (const char* e = std::getenv("NMGP_SEP")) c->sep_algo = (std::strcmp(e, "eig") == 0) ? 0 : 1;
     {
-        // The main stream carries the latency-bound panel steps of the factorisation, stream2 the far trailing updates
-        // that fill the chip: the main stream gets the higher priority so that its small kernels are dispatched as soon
-        // as a slot frees instead of queueing behind the update's workgroups.
+        // Two streams for the look-ahead factorisation: the main stream carries the latency-bound panel steps (and
+        // everything else of an evaluation), stream2 the far trailing updates that run under the NEXT panel's steps.
+        // An update tile holds a CU for ~100 us and two of them fill a CU's LDS, so a panel-step workgroup that shares the
+        // chip with an update in flight would wait for a tile to retire (stream priorities alone: measured, no gain).
+        // stream2 is therefore created with a CU MASK that leaves `la_cus` CUs -- the same CUs of every XCD: bit i of the
+        // mask is CU i / 8 of XCD i % 8 -- free of update tiles; the unmasked main stream finds them idle whenever an update
+        // is running, and uses the whole chip when none is.  NMGP_LOOKAHEAD_CUS=<n> (default 64; 0 = plain stream).
         int lo = 0, hi = 0;     // "greatest" (numerically lowest) priority is hi
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         const bool prio = std::getenv("NMGP_NO_STREAM_PRIORITY") == nullptr && lo != hi;
-        if (prio) {
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
-        } else {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (prio) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        int la_cus = 64;
+        if (const char* e = std::getenv("NMGP_LOOKAHEAD_CUS")) la_cus = std::atoi(e);
+        hipDeviceProp_t prop;
+        int ncu = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (la_cus > 0 && la_cus < ncu) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int i = la_cus; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                c->stream2 = nullptr;
+            } else {
+                c->stream2_cus = ncu - la_cus;
+            }
+        }
+        if (!c->stream2) {
+            if (prio) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+            else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         }
     }
     BLAS_TRY(c, rocblas_create_handle(&c->blas));

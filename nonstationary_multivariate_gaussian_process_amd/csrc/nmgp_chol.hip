@@ -735,6 +735,90 @@ __device__ __forceinline__ void potf2x_steps4(double (&a)[4], double (&e)[4], do
     potf2x_step<KC, 3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
 }
 
+// ---- 16x16 diagonal block in 4-column groups on the matrix cores (the default of phase (A) below) -------------------
+// The pivot-by-pivot variants above spend ~460 cycles per pivot, most of it waiting for cross-lane traffic (five exposed
+// ds_bpermute / v_readlane round trips per pivot).  Here the block lives in ONE wave's registers in the MFMA accumulator
+// layout -- S[i][j] in register i >> 2 of lane j + 16 (i & 3), kept SYMMETRIC, so that the four rows 4 g .. 4 g + 3 are
+// register g and are, as they stand, the B operand (and by symmetry the A operand) of a K = 4 MFMA -- and is factored four
+// columns at a time:
+//   * the 4x4 diagonal block is read into SGPRs (v_readlane, compile-time lanes) and factored by EVERY lane redundantly
+//     (uniform values, no cross-lane traffic), together with its inverse W;
+//   * X^T = W S[4g.., :]  (the column block of L and everything below it) is ONE v_mfma_f64_16x16x4_f64 whose result
+//     register 0 is, again without moving anything, both operands of the rank-4 update S -= X X^T (one more MFMA);
+//   * the same two operands carry the inverse along: Y = W E[4g.., :], E -= X Y, rows 4g.. of inv(L) = Y.
+// Critical path per four pivots: 20 v_readlane, the scalar 4x4 factorisation, two dependent MFMAs.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double t = d * y;
+    double e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    t = d * y;
+    e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+template <int G>
+__device__ __forceinline__ void potf2m_group(v4d& S, v4d& E, double& yfin, double* __restrict__ Sblk, int* __restrict__ info,
+                                             int goff, int lane, int l15, int l4) {
+    constexpr int b0 = 4 * G;
+    // the 4x4 diagonal block (lower part): S[b0 + a][b0 + b] sits in register G of lane (b0 + b) + 16 a
+    const double sg = S[G];
+    const double d00 = readlane_f64(sg, b0 + 0), d10 = readlane_f64(sg, b0 + 16), d11 = readlane_f64(sg, b0 + 17);
+    const double d20 = readlane_f64(sg, b0 + 32), d21 = readlane_f64(sg, b0 + 33), d22 = readlane_f64(sg, b0 + 34);
+    const double d30 = readlane_f64(sg, b0 + 48), d31 = readlane_f64(sg, b0 + 49), d32 = readlane_f64(sg, b0 + 50);
+    const double d33 = readlane_f64(sg, b0 + 51);
+    // Cholesky of the 4x4 block, every lane the same arithmetic; r_c = 1 / l_cc
+    const double r0 = rsqrt_nr(d00);
+    const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    const double p1 = fma(-l10, l10, d11);
+    const double r1 = rsqrt_nr(p1);
+    const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+    const double p2 = fma(-l21, l21, fma(-l20, l20, d22));
+    const double r2 = rsqrt_nr(p2);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+    const double r3 = rsqrt_nr(p3);
+    if (lane == 0) {
+        // first non-positive pivot of this group, LAPACK numbering (the NaN of a failed earlier pivot also lands here)
+        int bad = 0;
+        if (!(d00 > 0.0)) bad = 1;
+        else if (!(p1 > 0.0)) bad = 2;
+        else if (!(p2 > 0.0)) bad = 3;
+        else if (!(p3 > 0.0)) bad = 4;
+        if (bad) atomicCAS(info, 0, goff + b0 + bad);
+    }
+    // W = inv(L_gg), lower triangular
+    const double w10 = -(l10 * r0) * r1;
+    const double w21 = -(l21 * r1) * r2;
+    const double w32 = -(l32 * r2) * r3;
+    const double w20 = -fma(l21, w10, l20 * r0) * r2;
+    const double w31 = -fma(l32, w21, l31 * r1) * r3;
+    const double w30 = -fma(l32, w20, fma(l31, w10, l30 * r0)) * r3;
+    // A operand of the two "solve" MFMAs: lane n + 16 k carries W[n][k]
+    double a1 = 0.0;
+    a1 = (l15 == 0 && l4 == 0) ? r0 : a1;
+    a1 = (l15 == 1 && l4 == 0) ? w10 : a1;
+    a1 = (l15 == 1 && l4 == 1) ? r1 : a1;
+    a1 = (l15 == 2 && l4 == 0) ? w20 : a1;
+    a1 = (l15 == 2 && l4 == 1) ? w21 : a1;
+    a1 = (l15 == 2 && l4 == 2) ? r2 : a1;
+    a1 = (l15 == 3 && l4 == 0) ? w30 : a1;
+    a1 = (l15 == 3 && l4 == 1) ? w31 : a1;
+    a1 = (l15 == 3 && l4 == 2) ? w32 : a1;
+    a1 = (l15 == 3 && l4 == 3) ? r3 : a1;
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    // X^T = W S[b0.., :]: register 0 of the result holds X[i][n] in lane i + 16 n
+    const v4d xt = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sg, zero, 0, 0, 0);
+    const double x = xt[0];
+    S = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, x, S, 0, 0, 0);                   // S -= X X^T  (all four registers)
+    const v4d yt = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, E[G], zero, 0, 0, 0);   // Y = W E[b0.., :]
+    yfin = yt[0];
+    E = __builtin_amdgcn_mfma_f64_16x16x4f64(-x, yfin, E, 0, 0, 0);                // E -= X Y
+    // column block g of L (rows on and below its diagonal) goes back to the block in LDS
+    if (l15 >= b0 + l4) Sblk[(b0 + l4) * PB_LD + l15] = x;
+}
+
 // LDS working set of the blocked 64x64 diagonal factorisation (k_potf2_64b and the fused panel step)
 struct Potf2Lds {
     double S[64 * PB_LD];            // S[col * PB_LD + row]
@@ -752,7 +836,28 @@ __device__ __forceinline__ void potf2b_core(Potf2Lds& P, int* __restrict__ info,
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        if (w == 0 && xbar) {
+        if (w == 0 && xbar == 2) {
+            // (A), matrix-core flavour (see potf2m_group): S_qq symmetric in the accumulator layout, E = I
+            double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
+            v4d Sr, Er;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r, j = l15;
+                Sr[r] = (i >= j) ? Sqq[j * PB_LD + i] : Sqq[i * PB_LD + j];
+                Er[r] = (i == j) ? 1.0 : 0.0;
+            }
+            double y0, y1, y2, y3;
+            int* inf = info;
+            potf2m_group<0>(Sr, Er, y0, Sqq, inf, goff + 16 * q, lane, l15, l4);
+            potf2m_group<1>(Sr, Er, y1, Sqq, inf, goff + 16 * q, lane, l15, l4);
+            potf2m_group<2>(Sr, Er, y2, Sqq, inf, goff + 16 * q, lane, l15, l4);
+            potf2m_group<3>(Sr, Er, y3, Sqq, inf, goff + 16 * q, lane, l15, l4);
+            // rows 4 g + l4 of inv(L_qq)
+            P.Einv[q][l4][l15] = (l15 <= l4) ? y0 : 0.0;
+            P.Einv[q][4 + l4][l15] = (l15 <= 4 + l4) ? y1 : 0.0;
+            P.Einv[q][8 + l4][l15] = (l15 <= 8 + l4) ? y2 : 0.0;
+            P.Einv[q][12 + l4][l15] = (l15 <= 12 + l4) ? y3 : 0.0;
+        } else if (w == 0 && xbar) {
             // (A), register / crossbar flavour: thread (r, g) = (lane >> 2, lane & 3)
             const int r = lane >> 2, g = lane & 3;
             double a[4], e[4];
@@ -879,7 +984,8 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
 }
 
 static int g_potf2_valu = -1;     // NMGP_POTF2=valu selects the unblocked kernel (k_potf2_64)
-static int g_potf2_xbar = 1;      // NMGP_POTF2=lds: pivot steps of k_potf2_64b through an LDS column instead of DPP / bpermute
+static int g_potf2_xbar = 2;      // phase (A) of k_potf2_64b: 2 = 4-column groups on the matrix cores (default), 1 = pivot steps
+                                  // over DPP / bpermute (NMGP_POTF2=xbar), 0 = pivot steps through an LDS column (NMGP_POTF2=lds)
 // set by potrf_lower(precise = 1): substitution-based panel kernels (no inverted 16x16 blocks) for the ill-conditioned,
 // cached prior covariances (RBF + 1e-6 I, condition number up to 1e11), where the inverse-based solves cost parity digits
 static thread_local int g_precise = 0;
@@ -889,7 +995,7 @@ void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, in
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
-        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
+        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : ((e && std::strcmp(e, "xbar") == 0) ? 1 : 2);
     }
     if (g_potf2_valu || g_precise)
         NMGP_LAUNCH(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
@@ -901,7 +1007,7 @@ static int g_potf2_exports_inv() {
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
-        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : 1;
+        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : ((e && std::strcmp(e, "xbar") == 0) ? 1 : 2);
     }
     return (g_potf2_valu || g_precise) ? 0 : 1;
 }
@@ -1592,7 +1698,13 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         nb1 = (batch >= 16 && n >= 6144 && xtri == 0) ? 2048 : ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
     const int is = istride;
     const long long bs = bstride;
-    const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1);
+    // look-ahead pays where the panel steps are latency-bound: one matrix or a handful of subjects (the batched throughput
+    // path keeps every kernel exclusive); NMGP_CHOL_LA_MAX_BATCH moves the limit
+    static const int la_max_batch = [] {
+        const char* e = std::getenv("NMGP_CHOL_LA_MAX_BATCH");
+        return e ? std::atoi(e) : 16;
+    }();
+    const bool la = (s2 != nullptr && ev != nullptr && n > 2 * nb1 && batch <= la_max_batch && !precise);
     if (!la) {
         for (int c0 = 0; c0 < n; c0 += nb1) {
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
@@ -1617,12 +1729,14 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         hipEvent_t evPanel = ev[1 + 2 * k], evB = ev[2 + 2 * k];
         factor_panel(s, A, lda, n, extra, xtri, c0, w1, info, batch, bs, is);
         if (c1 >= n) break;
-        hipEventRecord(evPanel, s);
         // the previous far update also wrote the next panel's columns
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
         const int mact = active_rows(n, extra, xtri, c1);
         syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, mact - c1, w1n, w1, batch, bs, -1,
                    0);
+        // the far update starts only when the NEAR one is through: started together they share the chip and the near
+        // update -- which the next panel waits for -- takes 2-4x as long (96-227 us instead of ~45 in the kernel trace)
+        hipEventRecord(evPanel, s);
         prevB = false;
         if (c2 < n) {
             hipStreamWaitEvent(s2, evPanel, 0);

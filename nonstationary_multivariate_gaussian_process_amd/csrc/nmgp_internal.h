@@ -52,9 +52,10 @@ struct SyrkHook {
 struct nmgp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation
+    hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation (CU-masked, see nmgp_ctx_create)
+    int stream2_cus = 0;                     // CUs stream2 may use (0 = no mask)
     std::vector<hipEvent_t> chol_ev;          // events ordering the two streams
-    int chol_lookahead = 0;                   // far trailing update on stream2 (+-2 %; off keeps kernel timings exclusive)
+    int chol_lookahead = 1;                   // far trailing update on stream2 under the next panel (small batches only)
     SyrkHook syrk_hook;
     int sep_algo = 1;                         // separable/stationary likelihood: 1 = M batched Cholesky blocks, 0 = dsyevd
     rocblas_handle blas = nullptr;

@@ -46,7 +46,7 @@ print(json.dumps({"out": list(map(float, out)), "grad": list(map(float, grad)), 
                   "grad2": list(map(float, grad2)), "batch2": bout2.tolist(), "bgrad2": bgrad2.tolist()}))
 """
 
-VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "valu"}, {"NMGP_POTF2": "lds"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
+VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "valu"}, {"NMGP_POTF2": "lds"}, {"NMGP_POTF2": "xbar"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
             {"NMGP_SYRK_YROW": "0"}, {"NMGP_SYRK_HALF": "0"}, {"NMGP_SYRK_SWIZZLE": "0"},
             {"NMGP_CHOL_PANEL": "fused"}, {"NMGP_CHOL_PANEL": "rec"}, {"NMGP_CHOL_PANEL": "rl"},
             {"NMGP_CHOL_PANEL": "fused", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_PANEL": "fused", "NMGP_POTF2": "lds"},
