@@ -1351,7 +1351,8 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 //   state before step k (columns ck .. ck+63, ck = c0 + 64 k, panel = columns [c0, pend)):
 //     * columns < ck are final; the diagonal block (ck, ck) is factored, inverted 16x16 blocks in its upper part;
 //     * rows >= ck + 64 of the panel columns >= ck have received every column block < k - 1, but NOT block k - 1.
-//   step k, workgroups 0 .. T-1 ("solve" role, 8 waves x 16 rows each, rows >= ck + 64):
+//   step k, workgroups 0 .. T-1 ("solve" role, rows >= ck + 64; workgroup 0: the 64 rows of block row k + 1, the others
+//   8 waves x 16 rows each):
 //     1. catch-up: C[rows, block k] and C[rows, block k+1] -= X[rows, block k-1] L[.., block k-1]^T   (K = 64, MFMA; the
 //        operands are final since the previous launch, so no workgroup waits for another);
 //     2. solve: X[rows, block k] = C[rows, block k] inv(L_kk)^T  (the 16x16-blocked scheme of k_trsm_64f);
@@ -1363,12 +1364,21 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 // Critical path per step: one launch, two K = 64 MFMA passes over 64 rows, the 64x64 factorisation.
 // ---------------------------------------------------------------------------------------------
 #define PS_XLD 66
-#define PS_SMEM_DOUBLES (64 * PS_XLD + (int)(sizeof(Potf2Lds) / sizeof(double)))
+#define PS_XPS_OFF 6656                                  // after opsC (4096 doubles) and opsT (2560)
+#define PS_XS_OFF (PS_XPS_OFF + 64 * PS_XLD)
+#define PS_SMEM_DOUBLES (PS_XS_OFF + 64 * PS_XLD)        // 15104 doubles = 118 KB (the factorisation's LDS aliases the operands)
 
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
-                                                        int u_tiles, int nbatch, int xbar) {
+                                                        int u_tiles, int nbatch, int xbar, long long* __restrict__ stamps) {
+    // developer aid (NMGP_STEP_STAMPS=<file>): thread 0 of workgroup 0 of matrix 0 records the 100 MHz wall clock at the
+    // phase boundaries of the critical workgroup
+#define PS_STAMP(i)                                                              \
+    do {                                                                         \
+        if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)wall_clock64(); \
+    } while (0)
+    PS_STAMP(0);
     __shared__ __attribute__((aligned(32))) double smem[PS_SMEM_DOUBLES > 4 * SY_BK * SY_LD ? PS_SMEM_DOUBLES : 4 * SY_BK * SY_LD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1385,10 +1395,17 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     double* A = Ab + (size_t)blockIdx.y * bstride;
     v4d* opsC = reinterpret_cast<v4d*>(smem);                    // [4 q][4 sg][64 lanes]: -L[cb + 16 q + i][4 (4 sg + kk) + l4]
     v4d* opsT = reinterpret_cast<v4d*>(smem + 4096);             // [10][64 lanes], as in k_trsm_64f
-    const bool special = (blockIdx.x == 0) && has_next;
-    const int row = ck + 64 + 128 * (int)blockIdx.x + 16 * w + l15;
-    const bool rv = row < m_act;
-    const int rowc = rv ? row : (m_act - 1);                      // clamped: loads stay in bounds, results are masked
+    double* Xps = smem + PS_XPS_OFF;                             // [64][PS_XLD]: X[k+1, k-1] (workgroup 0)
+    double* Xs = smem + PS_XS_OFF;                               // [64][PS_XLD]: X[k+1, k]   (workgroup 0)
+    // Workgroup 0 owns the critical block row k + 1 ("C", waves 0..3: its diagonal block is factored at the end of this
+    // launch) and nothing else: its waves 4..7 only take part in the barriers.  The FP64 matrix pipe of a SIMD is shared by
+    // the waves on it, and the ~230 MFMAs per wave that lead up to the factorisation ARE the critical path; a second block
+    // row on the same CU doubled them (measured: 12.4 us against 7).
+    const bool wg0 = blockIdx.x == 0;
+    const bool isC = wg0 && w < 4;
+    const int row = wg0 ? ck + 64 + 16 * w + l15 : ck + 128 + 128 * ((int)blockIdx.x - 1) + 16 * w + l15;
+    const bool rv = row < m_act && !(wg0 && w >= 4);
+    const int rowc = row < m_act ? row : (m_act - 1);            // clamped: loads stay in bounds, results are masked
     // (1) issue every global load this thread needs up front
     double oc[8], ot[5];
     v4d Xp[4], Tk[4], Un[4];
@@ -1437,6 +1454,12 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
             const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
             smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
         }
+        if (isC && has_next) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xps[(16 * w + l15) * PS_XLD + 16 * q + 4 * r + l4] = Xp[q][r];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -1445,8 +1468,10 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         smem[4096 + (blk * 64 + l) * 4 + kk] = ot[j];
     }
     __syncthreads();
-    // operands of the second catch-up (column block k + 1) travel while the first one computes
-    if (has_prev && has_next) {
+    PS_STAMP(1);
+    // operands of the second catch-up (column block k + 1) travel while the first one computes (workgroup 0 takes them
+    // from Xps instead: they ARE block row k + 1 of column block k - 1)
+    if (has_prev && has_next && !wg0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
@@ -1454,16 +1479,18 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         }
     }
     // (3) catch-up of column block k:  T_q -= X_prev L_prev[block k, q]^T
-    if (has_prev) {
+    if (has_prev && (!wg0 || isC)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int sg = 0; sg < 4; ++sg)
 #pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                const v4d a = opsC[(q * 4 + sg) * 64 + lane];
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Xp[sg][kk], Tk[q], 0, 0, 0);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const double a = reinterpret_cast<const double*>(&opsC[(q * 4 + sg) * 64 + lane])[kk];
+                    Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xp[sg][kk], Tk[q], 0, 0, 0);
+                }
     }
+    PS_STAMP(2);
     // (4) solve against the diagonal block (right-looking over the four 16-column blocks, see k_trsm_64f)
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
@@ -1473,11 +1500,12 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         for (int kk = 0; kk < 4; ++kk) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], Tk[pp][kk], x0, 0, 0, 0);
         Tk[pp] = x0;
 #pragma unroll
-        for (int q = pp + 1; q < 4; ++q) {
-            const v4d a = opsT[((q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp) * 64 + lane];
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Tk[pp][kk], Tk[q], 0, 0, 0);
-        }
+            for (int q = pp + 1; q < 4; ++q) {
+                const double a = reinterpret_cast<const double*>(&opsT[((q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp) * 64 + lane])[kk];
+                Tk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tk[pp][kk], Tk[q], 0, 0, 0);
+            }
     }
     if (rv) {
 #pragma unroll
@@ -1485,26 +1513,28 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) A[(size_t)(ck + 16 * q + 4 * r + l4) * lda + row] = Tk[q][r];
     }
+    PS_STAMP(3);
     if (!has_next) return;                                        // uniform: last step of the panel
-    // (5) catch-up of column block k + 1
-    if (has_prev) {
-        __syncthreads();                                          // every wave is done with the operands of block k
+    if (!wg0) {
+        // (5) catch-up of column block k + 1
+        if (has_prev) {
+            __syncthreads();                                      // every wave is done with the operands of block k
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
-            smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                const v4d a = opsC[(q * 4 + sg) * 64 + lane];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Xp[sg][kk], Un[q], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) {
+                const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
+                smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
             }
-    }
-    if (!special) {
+            __syncthreads();
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double a = reinterpret_cast<const double*>(&opsC[(q * 4 + sg) * 64 + lane])[kk];
+                        Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xp[sg][kk], Un[q], 0, 0, 0);
+                    }
+        }
         if (rv) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1513,33 +1543,43 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         }
         return;
     }
-    // (6) look-ahead (workgroup 0): waves 0..3 hold block row k + 1 (rows ck+64 .. ck+127, always valid: has_next)
-    double* Xs = smem;                                            // [64 rows][PS_XLD]: X[k+1, k]
-    Potf2Lds& P = *reinterpret_cast<Potf2Lds*>(smem + 64 * PS_XLD);
-    __syncthreads();                                              // operands in LDS are dead from here on
-    if (w < 4) {
+    // (6) workgroup 0: U = (k+1, k+1) has received the column blocks <= k - 2 (update role of the previous launch); two MFMA
+    // passes with block row k + 1 itself as the other operand make it D:  pass 1, column block k - 1 (X[k+1, k-1], own rows of
+    // the previous step, exchanged through Xps);  pass 2, column block k (X[k+1, k], just solved, through Xs).
+    if (isC) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Xs[(16 * w + l15) * PS_XLD + 16 * q + 4 * r + l4] = Tk[q][r];
-    } else if (rv) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(size_t)(ck + 64 + 16 * q + 4 * r + l4) * lda + row] = Un[q][r];
-    }
-    __syncthreads();
-    if (w < 4) {
-        // D[own 16 rows, 16 q ..] = U_q - X[own rows] X[16 q + i]^T
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
+        if (has_prev) {
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double a = -Xps[(16 * q + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
+                        Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xp[sg][kk], Un[q], 0, 0, 0);
+                    }
+        }
+    }
+    PS_STAMP(4);
+    __syncthreads();                                              // X[k+1, k] is in Xs
+    PS_STAMP(5);
+    if (isC) {
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
                     const double a = -Xs[(16 * q + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
                     Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tk[sg][kk], Un[q], 0, 0, 0);
                 }
+    }
+    Potf2Lds& P = *reinterpret_cast<Potf2Lds*>(smem);            // aliases the operand area: dead after the next barrier
+    __syncthreads();
+    if (isC) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1549,8 +1589,12 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
             }
     }
     __syncthreads();
+    PS_STAMP(6);
     potf2b_core(P, info + (size_t)blockIdx.y * istride, ck + 64, xbar);
+    PS_STAMP(7);
     potf2b_store(A + (size_t)(ck + 64) * lda + (ck + 64), lda, 64, P, tid, 512);
+    PS_STAMP(8);
+#undef PS_STAMP
 }
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
@@ -1621,8 +1665,11 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
     factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
 }
 
-// One fused launch per 64-column step (k_panel_step).  Needs full 64-column blocks and the blocked diagonal factorisation
-// (inverted 16x16 blocks in the factor).
+// NMGP_STEP_STAMPS=<file>: per-step phase stamps of the critical workgroup (developer aid, tools/step_stamps.py)
+static long long* g_stamps = nullptr;        // device, 16 slots per 64-column step
+static int g_stamps_cap = 0;
+static const char* g_stamps_path = nullptr;
+
 static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                                int batch, long long bs, int is) {
     potf2_64(s, A + (size_t)c0 * lda + c0, lda, 64, info, c0, batch, bs, is);      // the panel's first diagonal block
@@ -1633,12 +1680,13 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         const int rows = m_act - (ck + 64);
         if (rows <= 0) continue;                     // last block of the matrix and nothing below it
         const int has_prev = k > 0, has_next = k + 1 < nk;
-        const int T = cdiv_c(rows, 128);
+        const int T = 1 + (rows > 64 ? cdiv_c(rows - 64, 128) : 0);     // workgroup 0: block row k + 1 alone
         SyrkPlan pl;
         const int u_m = m_act - (ck + 128), u_n = c0 + w - (ck + 128);
         if (has_prev && u_m > 0 && u_n > 0) pl = syrk_plan(lda, lda, u_m, u_n, 64, 1, 0, true);
+        long long* st = (g_stamps && ck / 64 < g_stamps_cap) ? g_stamps + (size_t)(ck / 64) * 16 : nullptr;
         NMGP_LAUNCH(k_panel_step, dim3(T + pl.tiles, batch), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
-                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar);
+                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar, st);
     }
 }
 
@@ -1686,6 +1734,34 @@ struct HookScope {
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
                  int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook, int precise) {
     HookScope hs(hook);
+    struct StampScope {          // allocate before, dump after the factorisation (synchronises: developer aid only)
+        hipStream_t s;
+        int nsteps;
+        StampScope(hipStream_t st, int n) : s(st), nsteps((n + 63) / 64) {
+            static const char* path = std::getenv("NMGP_STEP_STAMPS");
+            g_stamps_path = path;
+            if (!path) return;
+            if (g_stamps_cap < nsteps) {
+                if (g_stamps) hipFree(g_stamps);
+                if (hipMalloc((void**)&g_stamps, (size_t)nsteps * 16 * sizeof(long long)) != hipSuccess) g_stamps = nullptr;
+                g_stamps_cap = g_stamps ? nsteps : 0;
+            }
+            if (g_stamps) hipMemsetAsync(g_stamps, 0, (size_t)g_stamps_cap * 16 * sizeof(long long), s);
+        }
+        ~StampScope() {
+            if (!g_stamps_path || !g_stamps) return;
+            std::vector<long long> h((size_t)nsteps * 16);
+            hipStreamSynchronize(s);
+            hipMemcpy(h.data(), g_stamps, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(g_stamps_path, "w")) {
+                for (int k = 0; k < nsteps; ++k) {
+                    for (int j = 0; j < 9; ++j) std::fprintf(f, "%lld ", h[(size_t)k * 16 + j]);
+                    std::fprintf(f, "\n");
+                }
+                std::fclose(f);
+            }
+        }
+    } stamp_scope(s, n);
     struct PreciseScope {
         int prev;
         explicit PreciseScope(int p) : prev(g_precise) { g_precise = p; }
