@@ -156,7 +156,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
                                                int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
-                                               int nyr, double* sA0, double* sB0) {
+                                               int nyr, double* sA0, double* sB0, bool skip00 = false) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -207,7 +207,8 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     };
     // sub-tile strictly above the diagonal, or right of a half-width tile (ncw = 64: the j-side rows 64..127 of the staged
     // panel are real rows of A, just not columns of this update): nothing to do
-    const bool active = !(diag && (wi * 64 + 63 < wj * 32)) && (wj * 32 < ncw);
+    // skip00: the 64x64 block at the tile's origin (sub-tiles wi = 0, wj = 0, 1) is updated by another workgroup
+    const bool active = !(diag && (wi * 64 + 63 < wj * 32)) && (wj * 32 < ncw) && !(skip00 && wi == 0 && wj < 2);
     const int nk = K / BK;
     gload();
     // acc[p][s][tj][r]: i = row0 + wi*64 + 32p + 2*l15 + s ; j = col0 + wj*32 + 2*(l4 + 4r) + tj
@@ -340,6 +341,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     // doubles of LDS each
     const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
     const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
+    const bool skipq = (ktri & 128) != 0;     // the leading 64x64 block of tile (0, 0) belongs to somebody else (k_panel_step)
     const int yrow = nyr ? mrows : -1;
     ktri &= 1;
     constexpr int NT = 128 * NWJ;          // threads
@@ -412,7 +414,8 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         const int ncw = ncols - col0 >= SY_BM ? SY_BM : ncols - col0;
         if (row0 + SY_BM <= mrows && (ncw == SY_BM || (ncw == 64 && !nohalf)) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
             (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
-            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0]);
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
+                           skipq && bi == 0 && bj == 0);
             return;
         }
     }
@@ -453,6 +456,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
 
     // a wave whose sub-tile lies strictly above the diagonal has nothing to compute
     const bool active = !(diag && (wi * 64 + 63 < wj * CW));
+    const bool skip00g = skipq && bi == 0 && bj == 0;
     const int nk = (K + BK - 1) / BK;
     // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
     // first row contribute nothing; ktri also means beta = 0: C is OVERWRITTEN with -A A^T (no zero-fill, no read of C)
@@ -520,7 +524,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
                 for (int r = 0; r < 4; ++r) {
                     const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
                     const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
-                    if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
+                    if (i < mrows && j < ncols && i >= j && !(skip00g && i < 64 && j < 64)) C[(size_t)j * ldc + i] = acc[tj][ti][r];
                 }
     }
 }
@@ -759,8 +763,8 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 }
 
 template <int G>
-__device__ __forceinline__ void potf2m_group(v4d& S, v4d& E, double& yfin, double* __restrict__ Sblk, int* __restrict__ info,
-                                             int goff, int lane, int l15, int l4) {
+__device__ __forceinline__ void potf2m_group(v4d& S, v4d& E, double& yfin, double* __restrict__ Sblk, int& first_bad, int lane,
+                                             int l15, int l4) {
     constexpr int b0 = 4 * G;
     // the 4x4 diagonal block (lower part): S[b0 + a][b0 + b] sits in register G of lane (b0 + b) + 16 a
     const double sg = S[G];
@@ -779,14 +783,15 @@ __device__ __forceinline__ void potf2m_group(v4d& S, v4d& E, double& yfin, doubl
     const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
     const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
     const double r3 = rsqrt_nr(p3);
-    if (lane == 0) {
-        // first non-positive pivot of this group, LAPACK numbering (the NaN of a failed earlier pivot also lands here)
+    // first non-positive pivot so far, LAPACK numbering within the 16x16 block (the NaN of a failed earlier pivot also lands
+    // here); selects only -- a branch here would sit in the middle of the dependent chain
+    {
         int bad = 0;
-        if (!(d00 > 0.0)) bad = 1;
-        else if (!(p1 > 0.0)) bad = 2;
-        else if (!(p2 > 0.0)) bad = 3;
-        else if (!(p3 > 0.0)) bad = 4;
-        if (bad) atomicCAS(info, 0, goff + b0 + bad);
+        bad = !(p3 > 0.0) ? b0 + 4 : bad;
+        bad = !(p2 > 0.0) ? b0 + 3 : bad;
+        bad = !(p1 > 0.0) ? b0 + 2 : bad;
+        bad = !(d00 > 0.0) ? b0 + 1 : bad;
+        first_bad = first_bad ? first_bad : bad;
     }
     // W = inv(L_gg), lower triangular
     const double w10 = -(l10 * r0) * r1;
@@ -831,33 +836,101 @@ struct Potf2Lds {
 // Factor the 64x64 block held in P.S (lower triangle valid, strict upper zero).  Called by EVERY thread of the workgroup
 // (the barriers are workgroup barriers); threads 0..255 do the work, any further waves only take part in the barriers.
 // On return (after the trailing barrier) P.S holds L and P.Einv the inverted diagonal 16x16 blocks.
-__device__ __forceinline__ void potf2b_core(Potf2Lds& P, int* __restrict__ info, int goff, int xbar) {
+// The matrix-core flavour of the whole 64x64 factorisation (xbar == 2).  Wave 0 runs the critical chain WITHOUT waiting for
+// the others: after the 16x16 diagonal block q (potf2m_group x 4) and ONE barrier that publishes L_qq and inv(L_qq), it solves
+// block row q + 1 itself (4 MFMAs), updates the next diagonal tile (4 MFMAs) -- which never leaves its registers -- and goes
+// straight on to the next block.  Waves 1 and 2 bring the rows below up to date meanwhile (row q + 1 + w: X_i, the X_j it needs
+// recomputed rather than waited for, its tiles updated in LDS); the X blocks (final columns of L) are written back one
+// barrier later, when nobody reads the S they replace any more.  5 barriers instead of 10, none of them with the chain
+// waiting for non-critical work.
+__device__ __forceinline__ void potf2b_core_mfma(Potf2Lds& P, int* __restrict__ info, int goff) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    v4d Sr = {0.0, 0.0, 0.0, 0.0};          // wave 0: the current diagonal tile, symmetric, accumulator layout
+    v4d Xown = {0.0, 0.0, 0.0, 0.0};        // X[row block of this wave][column block q] of the previous iteration
+    if (w == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = l4 + 4 * r, j = l15;
+            Sr[r] = (i >= j) ? P.S[j * PB_LD + i] : P.S[i * PB_LD + j];
+        }
+    }
+    // X_i = S_iq inv(L_qq)^T for row block i (accumulator layout = operand layout: register kk is k-slice kk)
+    auto solve_rows = [&](int q, int i) {
+        v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double av = P.Einv[q][l15][4 * kk + l4];
+            const double bv = P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+        }
+        return x;
+    };
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        if (w == 0 && xbar == 2) {
-            // (A), matrix-core flavour (see potf2m_group): S_qq symmetric in the accumulator layout, E = I
+        if (w == 0) {
             double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
-            v4d Sr, Er;
+            v4d Er;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = l4 + 4 * r, j = l15;
-                Sr[r] = (i >= j) ? Sqq[j * PB_LD + i] : Sqq[i * PB_LD + j];
-                Er[r] = (i == j) ? 1.0 : 0.0;
-            }
+            for (int r = 0; r < 4; ++r) Er[r] = (l4 + 4 * r == l15) ? 1.0 : 0.0;
             double y0, y1, y2, y3;
-            int* inf = info;
-            potf2m_group<0>(Sr, Er, y0, Sqq, inf, goff + 16 * q, lane, l15, l4);
-            potf2m_group<1>(Sr, Er, y1, Sqq, inf, goff + 16 * q, lane, l15, l4);
-            potf2m_group<2>(Sr, Er, y2, Sqq, inf, goff + 16 * q, lane, l15, l4);
-            potf2m_group<3>(Sr, Er, y3, Sqq, inf, goff + 16 * q, lane, l15, l4);
-            // rows 4 g + l4 of inv(L_qq)
+            int first_bad = 0;
+            potf2m_group<0>(Sr, Er, y0, Sqq, first_bad, lane, l15, l4);
+            potf2m_group<1>(Sr, Er, y1, Sqq, first_bad, lane, l15, l4);
+            potf2m_group<2>(Sr, Er, y2, Sqq, first_bad, lane, l15, l4);
+            potf2m_group<3>(Sr, Er, y3, Sqq, first_bad, lane, l15, l4);
+            if (first_bad && lane == 0) atomicCAS(info, 0, goff + 16 * q + first_bad);
             P.Einv[q][l4][l15] = (l15 <= l4) ? y0 : 0.0;
             P.Einv[q][4 + l4][l15] = (l15 <= 4 + l4) ? y1 : 0.0;
             P.Einv[q][8 + l4][l15] = (l15 <= 8 + l4) ? y2 : 0.0;
             P.Einv[q][12 + l4][l15] = (l15 <= 12 + l4) ? y3 : 0.0;
-        } else if (w == 0 && xbar) {
+        }
+        __syncthreads();
+        // the X blocks of the previous iteration become column block q - 1 of L (their inputs are dead now)
+        if (q > 0 && w < 3 && q + w < 4) {
+            const int i = q + w;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) P.S[(16 * (q - 1) + l4 + 4 * reg) * PB_LD + 16 * i + l15] = Xown[reg];
+        }
+        if (q == 3) break;
+        const int i = q + 1 + w;            // row block of this wave in this iteration
+        if (w == 0) {
+            Xown = solve_rows(q, i);
+            // next diagonal tile, symmetric: S_ii - X_i X_i^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = l4 + 4 * r, b = l15;
+                Sr[r] = (a >= b) ? P.S[(16 * i + b) * PB_LD + 16 * i + a] : P.S[(16 * i + a) * PB_LD + 16 * i + b];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xown[kk], Xown[kk], Sr, 0, 0, 0);
+        } else if (w < 3 && i < 4) {
+            Xown = solve_rows(q, i);
+            for (int j = q + 1; j <= i; ++j) {
+                const v4d xj = (j == i) ? Xown : solve_rows(q, j);
+                v4d acc;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[reg] = P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xj[kk], Xown[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15] = acc[reg];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void potf2b_core(Potf2Lds& P, int* __restrict__ info, int goff, int xbar) {
+    if (xbar == 2) {
+        potf2b_core_mfma(P, info, goff);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        if (w == 0 && xbar) {
             // (A), register / crossbar flavour: thread (r, g) = (lane >> 2, lane & 3)
             const int r = lane >> 2, g = lane & 3;
             double a[4], e[4];
@@ -1371,7 +1444,8 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
-                                                        int u_tiles, int nbatch, int xbar, long long* __restrict__ stamps) {
+                                                        int u_tiles, int nbatch, int xbar, int pre,
+                                                        long long* __restrict__ stamps) {
     // developer aid (NMGP_STEP_STAMPS=<file>): thread 0 of workgroup 0 of matrix 0 records the 100 MHz wall clock at the
     // phase boundaries of the critical workgroup
 #define PS_STAMP(i)                                                              \
@@ -1403,6 +1477,13 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     // row on the same CU doubled them (measured: 12.4 us against 7).
     const bool wg0 = blockIdx.x == 0;
     const bool isC = wg0 && w < 4;
+    // Workgroup 1, waves 0..3 ("P"): block row k + 2, the critical rows of the NEXT launch.  They bring their own diagonal
+    // block (k+2, k+2) fully up to date -- column block k - 1 (its pending update, taken over from the update role, which
+    // skips that 64x64 block: flag 128) AND column block k (both operands are their own rows: X[k+2, k-1], X[k+2, k]) -- so
+    // that next launch's C finds only ONE pass left between its solve and the factorisation.  `pre` = block k + 2 is inside
+    // the panel.
+    const bool wg1 = pre && blockIdx.x == 1;
+    const bool isP = wg1 && w < 4;
     const int row = wg0 ? ck + 64 + 16 * w + l15 : ck + 128 + 128 * ((int)blockIdx.x - 1) + 16 * w + l15;
     const bool rv = row < m_act && !(wg0 && w >= 4);
     const int rowc = row < m_act ? row : (m_act - 1);            // clamped: loads stay in bounds, results are masked
@@ -1454,7 +1535,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
             const int e = tid + 512 * j, q = e >> 10, sx = (e >> 6) & 15, l = e & 63;
             smem[((q * 4 + (sx >> 2)) * 64 + l) * 4 + (sx & 3)] = oc[j];
         }
-        if (isC && has_next) {
+        if (isP) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1516,6 +1597,13 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     PS_STAMP(3);
     if (!has_next) return;                                        // uniform: last step of the panel
     if (!wg0) {
+        if (isP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xs[(16 * w + l15) * PS_XLD + 16 * q + 4 * r + l4] = Tk[q][r];
+        }
+        if (wg1 && !has_prev) __syncthreads();                    // (with has_prev the barriers of (5) publish Xs)
         // (5) catch-up of column block k + 1
         if (has_prev) {
             __syncthreads();                                      // every wave is done with the operands of block k
@@ -1541,27 +1629,55 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) A[(size_t)(ck + 64 + 16 * q + 4 * r + l4) * lda + row] = Un[q][r];
         }
+        if (isP) {
+            // only now (U is stored, its registers are free): the diagonal block (k+2, k+2), its pending column block k - 1
+            // and, eagerly, this step's column block: V -= X[k+2, k-1] X[k+2, k-1]^T + X[k+2, k] X[k+2, k]^T
+            // (two 16-column blocks at a time: the kernel sits at the VGPR limit)
+#pragma unroll 1
+            for (int q0 = 0; q0 < 4; q0 += 2) {
+                v4d Vn[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vn[qq][r] = A[(size_t)(ck + 128 + 16 * (q0 + qq) + 4 * r + l4) * lda + rowc];
+                if (has_prev) {
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                const double a = -Xps[(16 * (q0 + qq) + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
+                                const double b = Xps[(16 * w + l15) * PS_XLD + 16 * sg + 4 * kk + l4];     // own row, from LDS
+                                Vn[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Vn[qq], 0, 0, 0);
+                            }
+                }
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const double a = -Xs[(16 * (q0 + qq) + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
+                            const double b = Xs[(16 * w + l15) * PS_XLD + 16 * sg + 4 * kk + l4];          // (registers are scarce)
+                            Vn[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Vn[qq], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[(size_t)(ck + 128 + 16 * (q0 + qq) + 4 * r + l4) * lda + row] = Vn[qq][r];
+            }
+        }
         return;
     }
-    // (6) workgroup 0: U = (k+1, k+1) has received the column blocks <= k - 2 (update role of the previous launch); two MFMA
-    // passes with block row k + 1 itself as the other operand make it D:  pass 1, column block k - 1 (X[k+1, k-1], own rows of
-    // the previous step, exchanged through Xps);  pass 2, column block k (X[k+1, k], just solved, through Xs).
+    // (6) workgroup 0: U = (k+1, k+1) arrives with every column block < k applied (the update role up to k - 2, block k - 1 by
+    // the P waves of the previous launch, which also applied... nothing of this step: that is the one pass left):
+    // D = U - X[k+1, k] X[k+1, k]^T, block row k + 1 as both operands, exchanged through Xs.
     if (isC) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Xs[(16 * w + l15) * PS_XLD + 16 * q + 4 * r + l4] = Tk[q][r];
-        if (has_prev) {
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double a = -Xps[(16 * q + l15) * PS_XLD + 16 * sg + 4 * kk + l4];
-                        Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xp[sg][kk], Un[q], 0, 0, 0);
-                    }
-        }
     }
     PS_STAMP(4);
     __syncthreads();                                              // X[k+1, k] is in Xs
@@ -1590,7 +1706,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     }
     __syncthreads();
     PS_STAMP(6);
-    potf2b_core(P, info + (size_t)blockIdx.y * istride, ck + 64, xbar);
+    potf2b_core_mfma(P, info + (size_t)blockIdx.y * istride, ck + 64);     // (the fused schedule needs NMGP_POTF2 at its default)
     PS_STAMP(7);
     potf2b_store(A + (size_t)(ck + 64) * lda + (ck + 64), lda, 64, P, tid, 512);
     PS_STAMP(8);
@@ -1684,15 +1800,19 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         SyrkPlan pl;
         const int u_m = m_act - (ck + 128), u_n = c0 + w - (ck + 128);
         if (has_prev && u_m > 0 && u_n > 0) pl = syrk_plan(lda, lda, u_m, u_n, 64, 1, 0, true);
+        const int pre = (ck + 192 <= c0 + w) ? 1 : 0;            // block (k+2, k+2) lies inside the panel: see the P waves
+        if (pre) pl.kflags |= 128;                                // ... which own it: the update role skips that block
         long long* st = (g_stamps && ck / 64 < g_stamps_cap) ? g_stamps + (size_t)(ck / 64) * 16 : nullptr;
         NMGP_LAUNCH(k_panel_step, dim3(T + pl.tiles, batch), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
-                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar, st);
+                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar, pre, st);
     }
 }
 
 // panel schedule: NMGP_CHOL_PANEL = fused | rec | rl | auto (default)
 static int g_panel_mode = -1;      // 0 auto, 1 fused, 2 rec, 3 rl
-static int g_fused_max_batch = 16; // NMGP_CHOL_FUSED_MAX_BATCH: largest batch that takes the fused steps under auto
+static int g_fused_max_batch = -1; // NMGP_CHOL_FUSED_MAX_BATCH: largest batch that takes the fused steps under auto; default:
+                                   // batch * n <= 73728 (measured: n = 6144: 8 chains 523 vs 503 evals/s, 16 chains 418 vs 616;
+                                   // n = 3072: 16 subjects 3211 vs 2729, 24 subjects 3563, 32 subjects 2877 vs 3714)
 
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
@@ -1705,8 +1825,9 @@ static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, in
         g_panel_mode = !e ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : (std::strcmp(e, "rec") == 0 ? 2 : (std::strcmp(e, "rl") == 0 ? 3 : 0)));
         if (const char* m = std::getenv("NMGP_CHOL_FUSED_MAX_BATCH")) g_fused_max_batch = std::atoi(m);
     }
-    const bool can_fuse = (w % 64 == 0) && g_potf2_exports_inv() && (lda % 2 == 0);
-    if (can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && batch <= g_fused_max_batch)))
+    const bool can_fuse = (w % 64 == 0) && g_potf2_exports_inv() && g_potf2_xbar == 2 && (lda % 2 == 0);
+    const bool small = g_fused_max_batch >= 0 ? batch <= g_fused_max_batch : (long long)batch * n <= 73728;
+    if (can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && small)))
         factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
