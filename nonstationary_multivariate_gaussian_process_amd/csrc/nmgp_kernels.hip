@@ -703,30 +703,33 @@ void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int
 // Column j of subject b: r = R + (b * nrhs + j) * N; its factor is L0 for j = 0 and L1 for j >= 1 (strides s0 / s1).
 // ---------------------------------------------------------------------------------------------
 template <bool TRANS>
-__global__ __launch_bounds__(256) void k_prior_trsv(const double* __restrict__ L0, int ld0, long long s0,
-                                                     const double* __restrict__ L1, int ld1, long long s1,
-                                                     double* __restrict__ R, int N, int nrhs) {
+__global__ __launch_bounds__(1024) void k_prior_trsv(const double* __restrict__ L0, int ld0, long long s0,
+                                                      const double* __restrict__ L1, int ld1, long long s1,
+                                                      double* __restrict__ R, int N, int nrhs) {
     const int j = blockIdx.x, b = blockIdx.y;
     const double* L = (j == 0 ? L0 + (size_t)b * s0 : L1 + (size_t)b * s1);
     const int ld = (j == 0 ? ld0 : ld1);
     double* r = R + ((size_t)b * nrhs + j) * N;
     extern __shared__ double sh[];
-    double* rv = sh;                        // [N]   the right-hand side / solution
-    double* Ld = sh + N;                    // [64][65] diagonal block, Ld[c * 65 + r]
+    double* rv = sh;                        // [N + 1] the right-hand side / solution (one pad element for row pairs)
+    double* Ld = sh + N + 2;                // [64][65] diagonal block, Ld[c * 65 + r]
     double* xs = Ld + 64 * 65;              // [64]  the block's solution
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < N; i += 256) rv[i] = r[i];
+    for (int i = tid; i < N; i += 1024) rv[i] = r[i];
+    if (tid == 0) rv[N] = 0.0;
     const int nblk = (N + 63) / 64;
     for (int bb = 0; bb < nblk; ++bb) {
         const int kb = (TRANS ? nblk - 1 - bb : bb) * 64;
         const int nbk = N - kb < 64 ? N - kb : 64;
         __syncthreads();                    // rv up to date, Ld / xs free
-        for (int e = tid; e < 64 * 64; e += 256) {
+        for (int e = tid; e < 64 * 64; e += 1024) {
             const int rr = e & 63, cc = e >> 6;
             Ld[cc * 65 + rr] = (rr < nbk && cc <= rr) ? L[(size_t)(kb + cc) * ld + kb + rr] : (rr == cc ? 1.0 : 0.0);
         }
         __syncthreads();
         if (w == 0) {
+            // 64 substitution steps by one wave: lane = row of the block; x_k = v_k / L_kk by a true division (these are the
+            // ill-conditioned prior factors: no reciprocals, no inverted blocks), broadcast by v_readlane
             double v = lane < nbk ? rv[kb + lane] : 0.0;
             const double d = Ld[lane * 65 + lane];
             if (!TRANS) {
@@ -748,41 +751,88 @@ __global__ __launch_bounds__(256) void k_prior_trsv(const double* __restrict__ L
                     v = (lane == k) ? xk : (lane < k ? v - lki * xk : v);
                 }
             }
-            xs[lane] = v;
+            xs[lane] = (lane < nbk) ? v : 0.0;
             if (lane < nbk) rv[kb + lane] = v;
         }
         __syncthreads();
+        // The rest of the column block as a GEMV.  It is latency-bound on ONE workgroup's loads, so everything is laid out for
+        // loads in flight: 16 waves, a wave takes chunks of rows, its lanes split the 64 columns of the block 8 ways and every
+        // lane issues all its loads before the first use; the 8 partial sums meet by three xor-shuffles.
         if (!TRANS) {
-            // rows below the block: r[i] -= sum_k L[i][kb + k] x[k]   (coalesced along i)
-            for (int i = kb + 64 + tid; i < N; i += 256) {
-                double acc = rv[i];
-                const double* Lc = L + (size_t)kb * ld + i;
-#pragma unroll 8
-                for (int k = 0; k < 64; ++k) acc = fma(-Lc[(size_t)k * ld], xs[k], acc);
-                rv[i] = acc;
+            // rows below the block: r[i] -= sum_k L[i][kb + k] x[k].  lane = (row pair rp, k group kg): rows i0 + 2 rp, + 1;
+            // columns kb + 8 kg .. + 7 (16-byte loads along i, 128-byte segments per column)
+            const int rp = lane & 7, kg = lane >> 3;
+            double xk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xk[q] = xs[8 * kg + q];
+            const int first = kb + 64;
+            for (int i0 = first + 16 * w; i0 < N; i0 += 16 * 16) {
+                const int i = i0 + 2 * rp;
+                const bool v0 = i < N, v1 = i + 1 < N;
+                const int ic = v0 ? i : 0;          // (i, i + 1) with i + 1 == N reads the column's padding: ld > N for odd N
+                const double* Lc = L + (size_t)(kb + 8 * kg) * ld + ic;
+                double2 t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const double2*>(Lc + (size_t)q * ld);
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a0 = fma(t[q].x, xk[q], a0);
+                    a1 = fma(t[q].y, xk[q], a1);
+                }
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) {
+                    a0 += __shfl_xor(a0, m);
+                    a1 += __shfl_xor(a1, m);
+                }
+                if (kg == 0 && v0) rv[i] -= a0;
+                if (kg == 0 && v1) rv[i + 1] -= a1;
             }
         } else {
-            // columns left of the block: r[i] -= sum_k L[kb + k][i] x[k]   (64 contiguous doubles of column i)
-            for (int i = tid; i < kb; i += 256) {
-                double acc = rv[i];
-                const double* Lc = L + (size_t)i * ld + kb;
-#pragma unroll 8
-                for (int k = 0; k < 64; ++k) acc = fma(-(k < nbk ? Lc[k] : 0.0), xs[k], acc);
-                rv[i] = acc;
+            // columns left of the block: r[i] -= sum_k L[kb + k][i] x[k]: 64 contiguous doubles of column i.  lane = (k group
+            // kq of 8 contiguous k, column ii of 8): four 16-byte loads per lane
+            const int kq = lane & 7, ii = lane >> 3;
+            double xk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xk[q] = xs[8 * kq + q];
+            for (int i0 = 8 * w; i0 < kb; i0 += 8 * 16) {
+                const int i = i0 + ii;
+                const bool vi = i < kb;
+                const double* Lc = L + (size_t)(vi ? i : 0) * ld + kb + 8 * kq;
+                double2 t[4];
+                if (kb + 64 <= N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const double2*>(Lc + 2 * q);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        t[q].x = (8 * kq + 2 * q < nbk) ? Lc[2 * q] : 0.0;
+                        t[q].y = (8 * kq + 2 * q + 1 < nbk) ? Lc[2 * q + 1] : 0.0;
+                    }
+                }
+                double a0 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0 = fma(t[q].x, xk[2 * q], a0);
+                    a0 = fma(t[q].y, xk[2 * q + 1], a0);
+                }
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) a0 += __shfl_xor(a0, m);
+                if (kq == 0 && vi) rv[i] -= a0;
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < N; i += 256) r[i] = rv[i];
+    for (int i = tid; i < N; i += 1024) r[i] = rv[i];
 }
 
 void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
                 double* R, int N, int nrhs, int batch) {
-    const size_t lds = ((size_t)N + 64 * 65 + 64) * sizeof(double);
+    const size_t lds = ((size_t)N + 2 + 64 * 65 + 64) * sizeof(double);
     if (trans)
-        NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
     else
-        NMGP_LAUNCH(k_prior_trsv<false>, dim3(nrhs, batch), dim3(256), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<false>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
 }
 
 }  // namespace nmgpk
