@@ -275,6 +275,25 @@ def run_chains(a, rank, world, be):
                                          "per GPU", "bound": "mfma", "achieved": g_tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS},
                     "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in g_stage.items() if v[1] > 0}}
+    # end-to-end MCMC rate: BatchedHMC (drivers.py) advances the same B chains in lock-step, 20 leapfrog steps per sample
+    # (Nonseparable_model.py:228-231), every step one batched value+gradient launch sequence + the host-side leapfrog update
+    hmc_rec = None
+    if a.hmc_samples > 0 and prof is not None and max(1, min(a.groups, B)) == 1 and B > 1:
+        from nonstationary_multivariate_gaussian_process_amd import drivers
+        hmc = drivers.BatchedHMC(d["x"], d["Y"], hyper, allp, step_size=1e-4, num_steps_in_leap=20, seed=1, ctx=prof)
+        barrier(be, ev, world)
+        t0 = time.perf_counter()
+        samples, info = hmc.run(a.hmc_samples)
+        barrier(be, ev, world)
+        h_elapsed = max_over_ranks(time.perf_counter() - t0, world, be.device)
+        evals = (1 + 20 * a.hmc_samples) * B
+        hmc_rec = {"what": "BatchedHMC: %d chains in lock-step, 20 leapfrog steps per sample, step size 1e-4, identity mass "
+                           "matrix; one batched value+gradient evaluation per leapfrog step, parameters up / gradients down "
+                           "over PCIe every step" % B,
+                   "samples_per_s": a.hmc_samples * B * world / h_elapsed, "samples_per_chain": a.hmc_samples,
+                   "seconds": h_elapsed, "grad_evals_per_s": evals * world / h_elapsed,
+                   "accept_rate_mean": float(np.mean(info["accept_rate"])),
+                   "median_abs_energy_error": float(np.nanmedian(np.abs(info["energy_error"])))}
     # the ONE reduction: every chain of every rank contributes a row
     ids = [rank * B + b for b in range(B)]
     stats, table = chains.reduce_rows(unit_rows(ids, a.steps, out, status), B * world, world, device=be.device)
@@ -300,6 +319,8 @@ def run_chains(a, rank, world, be):
             rec.update(hip_chain_report(a, prof, stage, kprof, B, n, want_grad))
         if grad_rec is not None:
             rec["grad"] = grad_rec
+        if hmc_rec is not None:
+            rec["hmc"] = hmc_rec
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(d, allp[0], hyper, a.cpu_evals, want_grad)
     ev.close()
@@ -411,6 +432,8 @@ def parse_args(argv=None):
     ap.add_argument("--grad", action="store_true", help="time value+gradient evaluations as the headline")
     ap.add_argument("--grad-steps", type=int, default=3,
                     help="steps of the extra value+gradient measurement reported in the `grad` object (0 = skip)")
+    ap.add_argument("--hmc-samples", type=int, default=1,
+                    help="samples per chain of the BatchedHMC end-to-end measurement reported in the `hmc` object (0 = skip)")
     ap.add_argument("--workload", choices=["chain", "subjects"], default="chain",
                     help="chain: B chains of one N=2048 subject per GPU (headline); subjects: BASELINE config 4, "
                          "independent subjects of size --N sharded round-robin over the GPUs (8 per GPU), one batch each")

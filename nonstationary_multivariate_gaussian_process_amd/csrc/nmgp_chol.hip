@@ -336,7 +336,11 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
 template <int NWJ, int BK>
 __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int mrows,
                                                int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
-                                               int nbatch, int bx, int by, int bz0, double* sAb, double* sBb) {
+                                               int nbatch, int bx, int by, int bz0, double* sAb, double* sBb,
+                                               int tri_row0 = 0x7fffffff, int tri_k0 = 0) {
+    // tri_row0 / tri_k0: rows i >= tri_row0 of A are rows of an upper-triangular matrix riding below the factorisation (L^-T of
+    // the gradient evaluation): A[i, k] == 0 for k < (i - tri_row0) - tri_k0, so a tile made of such rows starts its k-loop
+    // there instead of multiplying zeros (with 1024-wide panels that was 12 % of the update flop, with 2048-wide ones 25 %)
     // (bx, by, bz0) = the launch's blockIdx, or the tile a fused kernel assigns to this workgroup; sAb / sBb: 2 * BK * SY_LD
     // doubles of LDS each
     const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
@@ -414,7 +418,12 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         const int ncw = ncols - col0 >= SY_BM ? SY_BM : ncols - col0;
         if (row0 + SY_BM <= mrows && (ncw == SY_BM || (ncw == 64 && !nohalf)) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
             (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
-            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, ktri ? row0 / BK : 0, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
+            int kt0f = ktri ? row0 / BK : 0;
+            if (row0 >= tri_row0) {
+                const int z = (row0 - tri_row0 - tri_k0) / BK;        // leading all-zero k-panels of this tile's rows
+                kt0f = z > 0 ? (z & ~1) : 0;                          // (the unrolled loop wants an even number of panels)
+            }
+            syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, kt0f, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
                            skipq && bi == 0 && bj == 0);
             return;
         }
@@ -460,7 +469,8 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     const int nk = (K + BK - 1) / BK;
     // ktri: A is upper triangular as a matrix (A[i, k] = 0 for k < i, e.g. L^-T), so the k-panels left of this tile's
     // first row contribute nothing; ktri also means beta = 0: C is OVERWRITTEN with -A A^T (no zero-fill, no read of C)
-    const int kt0 = ktri ? (row0 / BK) : 0;
+    int kt0 = ktri ? (row0 / BK) : 0;
+    if (row0 >= tri_row0 && row0 - tri_row0 - tri_k0 > 0) kt0 = (row0 - tri_row0 - tri_k0) / BK;
     gload(kt0 * BK);
     // The accumulators START as the C tile (the loads overlap the first panel fetch) and the j-side fragment enters
     // the MFMA negated, so the k-loop leaves C - A A^T in registers and the epilogue is stores only.
@@ -532,11 +542,11 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
 // C[i, j] -= sum_k A[i, k] A[j, k] on the lower trapezoid (see syrk_tile_body): 128x128 tiles, 8 waves of 64x32.
 __global__ __launch_bounds__(512, 4) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc,
                                                         int mrows, int ncols, int K, long long bstride, long long cstride,
-                                                        int ktri, int swz, int nbatch) {
+                                                        int ktri, int swz, int nbatch, int tri_row0, int tri_k0) {
     __shared__ double sA[2 * SY_BK * SY_LD];
     __shared__ double sB[2 * SY_BK * SY_LD];
     syrk_tile_body<4, SY_BK>(A, lda, C, ldc, mrows, ncols, K, bstride, cstride, ktri, swz, nbatch, blockIdx.x, blockIdx.y,
-                             blockIdx.z, sA, sB);
+                             blockIdx.z, sA, sB, tri_row0, tri_k0);
 }
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
@@ -595,7 +605,7 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
 }
 
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride, int ktri) {
+                long long bstride, long long cstride, int ktri, int tri_row0, int tri_k0) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
     const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false);
     const long long cs = cstride < 0 ? bstride : cstride;
@@ -606,7 +616,7 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
     }
     NMGP_LAUNCH(k_syrk_lower, pl.grid, dim3(512), 0, s, A, lda, C, ldc, pl.mrows, ncols, K, bstride, cs, pl.kflags,
-                       pl.swz, batch);
+                pl.swz, batch, tri_row0, tri_k0);
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 
@@ -1062,6 +1072,10 @@ static int g_potf2_xbar = 2;      // phase (A) of k_potf2_64b: 2 = 4-column grou
 // set by potrf_lower(precise = 1): substitution-based panel kernels (no inverted 16x16 blocks) for the ill-conditioned,
 // cached prior covariances (RBF + 1e-6 I, condition number up to 1e11), where the inverse-based solves cost parity digits
 static thread_local int g_precise = 0;
+static const int g_nb1_grad_wide = [] {      // NMGP_CHOL_GRAD_WIDE=0: 1024-wide panels when the L^-T rows ride along (A/B; with the
+    const char* e = std::getenv("NMGP_CHOL_GRAD_WIDE");   // zero k-panels of those rows skipped 2048 wins: 234.6 vs 233.6 at 64 chains)
+    return e ? std::atoi(e) : 1;
+}();
 
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride) {
@@ -1777,7 +1791,8 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
     const int c1 = c0 + h;
     const int below = active_rows(n, extra, xtri, c1) - c1;
     if (below > 0)
-        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0,
+                   xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
     factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
 }
 
@@ -1892,7 +1907,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, +2 % for 64 subjects of
     // n = 3072, slower for one chain or 8 subjects; 2048 loses 3 % when the L^-T rows ride along (gradient)
     if (nb1 <= 0)
-        nb1 = (batch >= 16 && n >= 6144 && xtri == 0) ? 2048 : ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
+        nb1 = (batch >= 16 && n >= 6144 && (xtri == 0 || g_nb1_grad_wide)) ? 2048 : ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
     const int is = istride;
     const long long bs = bstride;
     // look-ahead pays where the panel steps are latency-bound: one matrix or a handful of subjects (the batched throughput
@@ -1909,7 +1924,8 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
             const int c1 = c0 + w1;
             if (c1 < n)
                 syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda,
-                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0);
+                           active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0,
+                           xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
         }
         return;
     }
@@ -1930,7 +1946,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
         const int mact = active_rows(n, extra, xtri, c1);
         syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, mact - c1, w1n, w1, batch, bs, -1,
-                   0);
+                   0, xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
         // the far update starts only when the NEAR one is through: started together they share the chip and the near
         // update -- which the next panel waits for -- takes 2-4x as long (96-227 us instead of ~45 in the kernel trace)
         hipEventRecord(evPanel, s);
@@ -1938,7 +1954,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         if (c2 < n) {
             hipStreamWaitEvent(s2, evPanel, 0);
             syrk_lower(s2, A + (size_t)c0 * lda + c2, lda, A + (size_t)c2 * lda + c2, lda, mact - c2, n - c2, w1, batch,
-                       bs, -1, 0);
+                       bs, -1, 0, xtri > 0 ? n + extra - c2 : 0x7fffffff, c0);
             hipEventRecord(evB, s2);
             prevB = true;
         }

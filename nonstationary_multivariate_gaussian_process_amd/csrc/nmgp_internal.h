@@ -274,7 +274,7 @@ int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double*
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride = -1, int ktri = 0);
+                long long bstride, long long cstride = -1, int ktri = 0, int tri_row0 = 0x7fffffff, int tri_k0 = 0);
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch = 1, long long bstride = 0);
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride);

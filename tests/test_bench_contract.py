@@ -55,6 +55,8 @@ def test_bench_prints_one_valid_json_line(extra):
         gr = rec["grad"]
         assert gr["value"] > 0 and gr["chains_ok"] == B and gr["roofline"]["bound"] == "mfma" and gr["grad_norm_chain0"] > 0
         assert abs(gr["roofline"]["frac"] - gr["roofline"]["achieved"] / gr["roofline"]["peak"]) < 1e-12
+        if B > 1:
+            assert rec["hmc"]["samples_per_s"] > 0 and 0.0 <= rec["hmc"]["accept_rate_mean"] <= 1.0
     else:
         assert "grad" not in rec and "gradients" in rec["config"]["host_reads_per_step"]
     assert rl["traffic"] is None and rl["traffic_note"]          # no PMC measurement exists for this toy size
