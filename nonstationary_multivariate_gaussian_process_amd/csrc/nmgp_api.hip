@@ -251,9 +251,16 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
             else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         }
     }
+    if (const char* e = std::getenv("NMGP_PRIOR_OVERLAP")) c->prior_overlap = std::atoi(e);
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_prior, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prior_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prior_join, hipEventDisableTiming));
     BLAS_TRY(c, rocblas_create_handle(&c->blas));
     BLAS_TRY(c, rocblas_set_stream(c->blas, c->stream));
     BLAS_TRY(c, rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host));
+    BLAS_TRY(c, rocblas_create_handle(&c->blas_prior));
+    BLAS_TRY(c, rocblas_set_stream(c->blas_prior, c->stream_prior));
+    BLAS_TRY(c, rocblas_set_pointer_mode(c->blas_prior, rocblas_pointer_mode_host));
     NMGP_TRY(nmgp_dev_alloc(c, &c->d_scal, SC_COUNT));
     HIP_TRY(c, hipMalloc((void**)&c->d_info, 8 * sizeof(int)));
     HIP_TRY(c, hipHostMalloc((void**)&c->h_pin, SC_COUNT * sizeof(double)));
@@ -286,11 +293,18 @@ extern "C" int nmgp_ctx_destroy(nmgp_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_info) hipHostFree(c->h_info);
     if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->blas_prior) rocblas_destroy_handle(c->blas_prior);
     if (c->stream2) {
         hipStreamSynchronize(c->stream2);
         hipStreamDestroy(c->stream2);
     }
     for (auto e : c->chol_ev) hipEventDestroy(e);
+    if (c->stream_prior) {
+        hipStreamSynchronize(c->stream_prior);
+        hipStreamDestroy(c->stream_prior);
+    }
+    if (c->ev_prior_fork) hipEventDestroy(c->ev_prior_fork);
+    if (c->ev_prior_join) hipEventDestroy(c->ev_prior_join);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -446,6 +460,11 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     }
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, sizeof(int), s));
     if (nmgp_poison()) HIP_TRY(c, hipMemsetAsync(sc + SC_OUT, 0xFF, 8 * sizeof(double), s));   // stale results must not survive
+    // The GP priors depend on the parameter vector only: they run on their own stream under the factorisation.  The fork
+    // event is recorded HERE (so that stream does not wait for the factorisation), the solves themselves are enqueued after the
+    // factorisation's launches: the host needs ~0.2 ms for the library's ~40 small launches, which must not delay the first
+    // panel step.
+    PriorStreamScope ps(c);
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->d_pars, N, M, c->d_ell, c->d_Lv);
@@ -497,34 +516,36 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         chol_logdet_quad(s, c->d_S, ld, n, c->d_z, sc + SC_LOGDET, sc + SC_QUAD);
     }
     {
-        StageScope sp(c, NMGP_STAGE_PRIOR);
+        NmgpStage sp(c, NMGP_STAGE_PRIOR, ps.sp, 0.0, 0.0);
         const double one = 1.0;
-        svc_prior_rhs(s, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
+        svc_prior_rhs(ps.sp, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
         // (a single subject's 1 + T columns stay with the library: k_prior_trsv needs tens of workgroups to win, its
         // 7 workgroups took 0.69 ms against 0.26 ms at N = 2048)
         if (pl == pL) {
-            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+            BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                       rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R, N));
         } else {
-            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+            BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                       rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, c->d_R, N));
-            BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+            BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                       rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, c->d_R + N, N));
         }
-        col_sumsq(s, c->d_R, N, N, 1 + T, sc + SC_PRIORQ);
+        col_sumsq(ps.sp, c->d_R, N, N, 1 + T, sc + SC_PRIORQ);
         if (want_grad && prior) {
-            HIP_TRY(c, hipMemcpyAsync(c->d_R2, c->d_R, (size_t)N * (1 + T) * sizeof(double), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(c->d_R2, c->d_R, (size_t)N * (1 + T) * sizeof(double), hipMemcpyDeviceToDevice, ps.sp));
             if (pl == pL) {
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                           rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R2, N));
             } else {
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                           rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, c->d_R2, N));
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                           rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, c->d_R2 + N, N));
             }
         }
     }
+    ps.done();
+    ps.join();
     {
         StageScope sp(c, NMGP_STAGE_REDUCE);
         const double ig_const = a * std::log(b) - std::lgamma(a);   // distributions.py:134
@@ -791,6 +812,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     }
     HIP_TRY(c, hipMemsetAsync(c->b_info, 0, (size_t)B * sizeof(int), s));
     if (nmgp_poison()) HIP_TRY(c, hipMemsetAsync(c->b_scal, 0xFF, (size_t)B * 16 * sizeof(double), s));
+    PriorStreamScope ps(c);          // fork now, enqueue the prior solves after the factorisation (see svc_enqueue)
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
@@ -819,52 +841,54 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         chol_logdet_quad(s, S, ld, n, c->b_z, c->b_scal, c->b_scal + 1, B, bs, 16);
     }
     {
-        StageScope sp(c, NMGP_STAGE_PRIOR);
+        NmgpStage sp(c, NMGP_STAGE_PRIOR, ps.sp, 0.0, 0.0);
         const double one = 1.0;
-        svc_prior_rhs(s, c->b_pars, N, T, mu_l, mu_L, c->b_R, N, B);
+        svc_prior_rhs(ps.sp, c->b_pars, N, T, mu_l, mu_L, c->b_R, N, B);
         const bool same = (pl == pL);
         for (int pass = 0; pass < ((want_grad && prior) ? 2 : 1); ++pass) {
             double* R = pass == 0 ? c->b_R : c->b_R2;
             const rocblas_operation op = pass == 0 ? rocblas_operation_none : rocblas_operation_transpose;
             if (pass == 1)
                 HIP_TRY(c, hipMemcpyAsync(c->b_R2, c->b_R, (size_t)N * B * (1 + T) * sizeof(double),
-                                          hipMemcpyDeviceToDevice, s));
+                                          hipMemcpyDeviceToDevice, ps.sp));
             if (multi && N <= 3500 && B * (1 + T) >= 32 && !c->prior_rocblas) {
                 // per-subject factors, a handful of right-hand sides each: one streaming pass per column (k_prior_trsv)
-                prior_trsv(s, pass == 1, pl->L, pl->ld, (long long)pl->ld * N, pL->L, pL->ld, (long long)pL->ld * N, R, N, 1 + T,
+                prior_trsv(ps.sp, pass == 1, pl->L, pl->ld, (long long)pl->ld * N, pL->L, pL->ld, (long long)pL->ld * N, R, N, 1 + T,
                            (int)B);
             } else if (multi) {
                 // per-subject factors: strided-batched solves (columns of chain b start at b (1+T) N)
                 const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;
                 const rocblas_stride sB = (rocblas_stride)(1 + T) * N;
                 if (same) {
-                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
                                                               rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, sA_l,
                                                               R, N, sB, B));
                 } else {
-                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
                                                               rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, sA_l, R,
                                                               N, sB, B));
-                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                    BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
                                                               rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, sA_L,
                                                               R + N, N, sB, B));
                 }
             } else if (same) {
                 // one multi-right-hand-side solve for the whole batch: the prior factor depends on (x, alpha, beta) only
-                BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
+                BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
                                           B * (1 + T), &one, pl->L, pl->ld, R, N));
             } else {
                 for (int z = 0; z < B; ++z) {
                     double* Rz = R + (size_t)z * (1 + T) * N;
-                    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                    BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
                                               rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, Rz, N));
-                    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, op,
+                    BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
                                               rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, Rz + N, N));
                 }
             }
-            if (pass == 0) col_sumsq(s, c->b_R, N, N, B * (1 + T), c->b_q);
+            if (pass == 0) col_sumsq(ps.sp, c->b_R, N, N, B * (1 + T), c->b_q);
         }
     }
+    ps.done();
+    ps.join();
     {
         StageScope sp(c, NMGP_STAGE_REDUCE);
         const double ig_const = a * std::log(b) - std::lgamma(a);

@@ -245,14 +245,14 @@ void dB_to_guL(const std::vector<double>& dB, const std::vector<double>& L, int 
 
 // log N(v; mu 1, RBF(x; alpha, beta) + jitter I) for the columns of R (already v - mu), via the cached factor.
 // q_out[k] = Mahalanobis term of column k; if R2 != null also Sigma^-1 r (for the gradient).
-int prior_solve(nmgp_ctx* c, PriorFactor* pf, double* R, int ncol, double* R2) {
+int prior_solve(nmgp_ctx* c, rocblas_handle hb, hipStream_t sp, PriorFactor* pf, double* R, int ncol, double* R2) {
     const double one = 1.0;
     const int N = c->N;
-    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+    BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                               rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
     if (R2) {
-        HIP_TRY(c, hipMemcpyAsync(R2, R, (size_t)N * ncol * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+        HIP_TRY(c, hipMemcpyAsync(R2, R, (size_t)N * ncol * sizeof(double), hipMemcpyDeviceToDevice, sp));
+        BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                   rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R2, N));
     }
     return 0;
@@ -453,6 +453,26 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         exp_vec(s, c->d_pars, N, c->d_ell);
         exp_vec(s, c->d_pars + N, N, c->d_sig);
     }
+    // prior factors (cached; created and synchronised on first use) and the prior solves, which depend on the parameters
+    // only: queued on the prior stream so that they run under the likelihood's factorisation
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    PriorStreamScope pscope(c);
+    {
+        NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
+        two_col_rhs(pscope.sp, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
+        double* R2 = (grad && prior) ? c->d_R2 : nullptr;
+        if (pl == ps) {
+            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 2, R2));
+        } else {
+            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 1, R2));
+            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, c->d_R + N, 1, R2 ? R2 + N : nullptr));
+        }
+        col_sumsq(pscope.sp, c->d_R, N, N, 2, c->d_scal + 2);
+    }
+    pscope.done();
     double hs[4], loglik;
     CholKron ck;
     int attempts = 0;
@@ -460,24 +480,11 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         NmgpStage sp(c, NMGP_STAGE_COV);
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
     }, hs, &loglik, &ck, &attempts));
-    // GP priors on tilde_l and tilde_sigma (logpos.py:271-281)
-    PriorFactor *pl = nullptr, *ps = nullptr;
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
-    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    // GP priors on tilde_l and tilde_sigma (logpos.py:271-281): solved on the prior stream (queued before the likelihood)
     double q[2], hl[2];
     {
-        NmgpStage sp(c, NMGP_STAGE_PRIOR);
-        two_col_rhs(s, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
-        double* R2 = (grad && prior) ? c->d_R2 : nullptr;
-        if (pl == ps) {
-            NMGP_TRY(prior_solve(c, pl, c->d_R, 2, R2));
-        } else {
-            NMGP_TRY(prior_solve(c, pl, c->d_R, 1, R2));
-            NMGP_TRY(prior_solve(c, ps, c->d_R + N, 1, R2 ? R2 + N : nullptr));
-        }
-        col_sumsq(s, c->d_R, N, N, 2, w.sums + 8);
-        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 72, w.sums + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        pscope.join();
+        HIP_TRY(c, hipMemcpyAsync(c->h_pin + 72, c->d_scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 74, pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 75, ps->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));

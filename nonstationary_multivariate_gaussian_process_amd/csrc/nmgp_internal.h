@@ -54,6 +54,12 @@ struct nmgp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // look-ahead stream of the custom factorisation (CU-masked, see nmgp_ctx_create)
     int stream2_cus = 0;                     // CUs stream2 may use (0 = no mask)
+    // The GP-prior solves depend on the parameter vector only: they run on their own stream under the factorisation, whose
+    // latency-bound panel steps leave most of the chip idle (NMGP_PRIOR_OVERLAP=0: on the main stream, after the factorisation)
+    hipStream_t stream_prior = nullptr;
+    rocblas_handle blas_prior = nullptr;      // its own handle (own workspace): no stream switching on the main one
+    hipEvent_t ev_prior_fork = nullptr, ev_prior_join = nullptr;
+    int prior_overlap = 1;
     std::vector<hipEvent_t> chol_ev;          // events ordering the two streams
     int chol_lookahead = 1;                   // far trailing update on stream2 under the next panel (small batches only)
     SyrkHook syrk_hook;
@@ -184,6 +190,37 @@ int nmgp_take_launch_error(nmgp_ctx* c);
         int r__ = (expr);       \
         if (r__ != 0) return r__; \
     } while (0)
+
+// Fork / join of the prior stream: everything queued on the main stream so far is visible to the prior work, and the main
+// stream waits for it before the scalar epilogue (rocBLAS follows the stream it is told).
+struct PriorStreamScope {
+    nmgp_ctx* c;
+    hipStream_t sp;            // stream of the prior work
+    rocblas_handle hb;         // ... and the rocBLAS handle bound to it
+    bool forked = false, pending = false;
+    explicit PriorStreamScope(nmgp_ctx* ctx) : c(ctx), sp(ctx->stream), hb(ctx->blas) {
+        if (!c->prior_overlap || !c->stream_prior || !c->blas_prior) return;
+        if (hipEventRecord(c->ev_prior_fork, c->stream) != hipSuccess) return;
+        if (hipStreamWaitEvent(c->stream_prior, c->ev_prior_fork, 0) != hipSuccess) return;
+        sp = c->stream_prior;
+        hb = c->blas_prior;
+        forked = true;
+    }
+    void done() {              // end of the prior work: join event recorded
+        if (!forked) return;
+        hipEventRecord(c->ev_prior_join, c->stream_prior);
+        forked = false;
+        pending = true;
+    }
+    void join() {              // before the first consumer on the main stream
+        if (pending) hipStreamWaitEvent(c->stream, c->ev_prior_join, 0);
+        pending = false;
+    }
+    ~PriorStreamScope() {
+        done();
+        join();
+    }
+};
 
 // ---- kernel launchers (nmgp_kernels.hip) -------------------------------------------------------
 const SyrkHook* nmgp_syrk_hook(nmgp_ctx* c);

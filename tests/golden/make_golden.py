@@ -342,6 +342,25 @@ def gen_logpdf1(only):
     save(name, **out)
 
 
+def gen_local_estimation(only):
+    """empirical_estimation.local_estimation (empirical_estimation.py:71-133) on one simulated subject, two window sizes."""
+    name = "init_local_estimation_N90_M2"
+    if only and not name.startswith(only):
+        return
+    from Utility import empirical_estimation as EE
+    d = sim.simulate_nonseparable(90, 2, seed=4)
+    out = dict(x=d["x"], Y=d["Y"])
+    for W in (12, 30):
+        t0 = time.time()
+        es, el, sl, st, R, B, Lv, tse = EE.local_estimation(d["x"], d["Y"], window_size=W)
+        out.update({"w%d_sigmas" % W: es, "w%d_ls" % W: el, "w%d_smooth_ls" % W: sl, "w%d_stds" % W: st, "w%d_R" % W: R,
+                    "w%d_B" % W: B, "w%d_L_vecs" % W: Lv, "w%d_tse" % W: float(tse)})
+        print("  local_estimation W=%d: %.1f s" % (W, time.time() - t0), flush=True)
+    S, Lg = EE.global_estimation(d["x"], d["Y"])
+    out.update(global_S=S, global_L_vec=Lg)
+    save(name, **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -356,3 +375,4 @@ if __name__ == "__main__":
     gen_cfg4(a.only)
     gen_sep_big(a.only)
     gen_logpdf1(a.only)
+    gen_local_estimation(a.only)
