@@ -1907,7 +1907,9 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, +2 % for 64 subjects of
     // n = 3072, slower for one chain or 8 subjects; 2048 loses 3 % when the L^-T rows ride along (gradient)
     if (nb1 <= 0)
-        nb1 = (batch >= 16 && n >= 6144 && (xtri == 0 || g_nb1_grad_wide)) ? 2048 : ((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) ? 1024 : 512;
+        nb1 = (batch >= 16 && n >= 6144 && (xtri == 0 || g_nb1_grad_wide)) ? 2048
+              : (((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) && (long long)batch * n > 73728) ? 1024 : 512;
+    // (batches small enough for the fused panel steps keep 512: separable N = 4096, D = 5: 4.39 ms against 4.55 with 1024)
     const int is = istride;
     const long long bs = bstride;
     // look-ahead pays where the panel steps are latency-bound: one matrix or a handful of subjects (the batched throughput

@@ -7,6 +7,8 @@
 // (nmgp_kernels_eig.hip) or rocBLAS GEMM/TRSM.
 #include <algorithm>
 
+#include <functional>
+
 #include "nmgp_internal.h"
 
 using namespace nmgpk;
@@ -164,6 +166,17 @@ int setup_small(nmgp_ctx* c, EigWork& w, int M, int N, double sigma2) {
     return 0;
 }
 
+// Work the caller wants queued once the likelihood's launches are out and before the host blocks on their results (the
+// separable objective's prior solves: enqueued earlier they would delay the first panel step by the ~0.2 ms the host needs for
+// the library's small launches; enqueued here they run on their own stream under the factorisation).  Runs at most once.
+static thread_local std::function<int()>* g_before_sync = nullptr;
+static int run_before_sync() {
+    if (!g_before_sync) return 0;
+    std::function<int()>* f = g_before_sync;
+    g_before_sync = nullptr;
+    return (*f)();
+}
+
 // loglik of N(0, B kron K + sigma2 I) at the vector d_yv (output-major, device), K's lower triangle in c->d_K.
 // On return: V in d_K, wK, a (scaled by w if want_scaled), sums[0..3] on the host in hs.
 int kron_loglik(nmgp_ctx* c, EigWork& w, const double* d_yv, double sigma2, bool want_scaled, double hs[4],
@@ -180,6 +193,7 @@ int kron_loglik(nmgp_ctx* c, EigWork& w, const double* d_yv, double sigma2, bool
         eig_reduce(c->stream, w.a, w.wB, M, w.wK, N, w.sig2, want_scaled, w.sums);
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_pin + 64, w.sums, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NMGP_TRY(run_before_sync());
     NMGP_TRY(check_eig_info(c));
     for (int k = 0; k < 4; ++k) hs[k] = c->h_pin[64 + k];
     *loglik = -0.5 * hs[0] - 0.5 * hs[1];                                   // distributions.py:51
@@ -299,6 +313,7 @@ int kron_chol_loglik(nmgp_ctx* c, EigWork& w, double sigma2, bool want_grad, dou
     }
     std::vector<double> hr((size_t)M * 4);
     std::vector<int> hi(M);
+    NMGP_TRY(run_before_sync());
     HIP_TRY(c, hipMemcpyAsync(hr.data(), red, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -459,20 +474,27 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
     NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
-    PriorStreamScope pscope(c);
-    {
-        NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
-        two_col_rhs(pscope.sp, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
-        double* R2 = (grad && prior) ? c->d_R2 : nullptr;
-        if (pl == ps) {
-            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 2, R2));
-        } else {
-            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 1, R2));
-            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, c->d_R + N, 1, R2 ? R2 + N : nullptr));
+    PriorStreamScope pscope(c);          // fork now; the solves are queued by the hook, after the likelihood's launches
+    std::function<int()> enqueue_priors = [&]() -> int {
+        {
+            NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
+            two_col_rhs(pscope.sp, c->d_pars, mu_l, c->d_pars + N, mu_s, N, c->d_R);
+            double* R2 = (grad && prior) ? c->d_R2 : nullptr;
+            if (pl == ps) {
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 2, R2));
+            } else {
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, c->d_R, 1, R2));
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, c->d_R + N, 1, R2 ? R2 + N : nullptr));
+            }
+            col_sumsq(pscope.sp, c->d_R, N, N, 2, c->d_scal + 2);
         }
-        col_sumsq(pscope.sp, c->d_R, N, N, 2, c->d_scal + 2);
-    }
-    pscope.done();
+        pscope.done();
+        return 0;
+    };
+    g_before_sync = &enqueue_priors;
+    struct HookReset {
+        ~HookReset() { g_before_sync = nullptr; }
+    } hook_reset;
     double hs[4], loglik;
     CholKron ck;
     int attempts = 0;
@@ -480,9 +502,10 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         NmgpStage sp(c, NMGP_STAGE_COV);
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
     }, hs, &loglik, &ck, &attempts));
-    // GP priors on tilde_l and tilde_sigma (logpos.py:271-281): solved on the prior stream (queued before the likelihood)
+    // GP priors on tilde_l and tilde_sigma (logpos.py:271-281): solved on the prior stream under the likelihood
     double q[2], hl[2];
     {
+        NMGP_TRY(run_before_sync());      // (not yet queued if the likelihood returned before its first synchronisation)
         pscope.join();
         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 72, c->d_scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(c->h_pin + 74, pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
