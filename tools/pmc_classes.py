@@ -1,0 +1,57 @@
+"""HBM traffic of k_syrk_lower per launch class (K, ncols) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py.
+
+usage: python tools/pmc_classes.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json [n] [nb1] [batch] [extra]
+
+Replays the batched factorisation's launch schedule (recursive-halving panels + trailing updates, as tools/syrk_classes.py)
+to attach (rows, ncols, K) to the SYRK dispatches of the LAST evaluation in each pass, then reports per class the measured
+bytes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, counter unit KB) next to the algorithmic bytes
+(read + write of the updated trapezoid + the panel once) -- i.e. WHERE the excess traffic of the update kernel lands."""
+import csv
+import json
+import sys
+from collections import OrderedDict
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+from syrk_classes import schedule  # noqa: E402
+
+
+def last_eval_syrk(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    fin = [i for i, r in enumerate(rows) if "k_svc_finalize" in r["Kernel_Name"]]
+    ev = rows[fin[-2] + 1: fin[-1] + 1] if len(fin) > 1 else rows
+    return [float(r["Counter_Value"]) for r in ev if "k_syrk_lower" in r["Kernel_Name"]]
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 6144
+    nb1 = int(sys.argv[5]) if len(sys.argv) > 5 else 2048
+    batch = int(sys.argv[6]) if len(sys.argv) > 6 else 128
+    extra = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    sched = schedule(n, nb1, extra)
+    f, w = last_eval_syrk(fetch), last_eval_syrk(write)
+    if len(f) != len(sched) or len(w) != len(sched):
+        raise SystemExit("launch count mismatch: fetch %d, write %d, schedule %d" % (len(f), len(w), len(sched)))
+    cls = OrderedDict()
+    for (m, nc, K), fk, wk in zip(sched, f, w):
+        elems = nc * m - 0.5 * nc * (nc - 1)
+        c = cls.setdefault("K=%d" % K, {"launches": 0, "measured_bytes": 0.0, "algorithmic_bytes": 0.0, "flop": 0.0})
+        c["launches"] += 1
+        c["measured_bytes"] += 1024.0 * (2.0 * fk + wk)
+        c["algorithmic_bytes"] += 8.0 * batch * (2.0 * elems + m * K)
+        c["flop"] += 2.0 * K * elems * batch
+    tot_m = sum(c["measured_bytes"] for c in cls.values())
+    tot_a = sum(c["algorithmic_bytes"] for c in cls.values())
+    for c in cls.values():
+        c["ratio"] = c["measured_bytes"] / c["algorithmic_bytes"]
+        c["flop_per_measured_byte"] = c["flop"] / c["measured_bytes"]
+    res = {"n": n, "nb1": nb1, "batch": batch, "classes": cls, "total_measured_bytes": tot_m,
+           "total_algorithmic_bytes": tot_a, "ratio": tot_m / tot_a,
+           "note": "FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB counters; k_syrk_lower launches of the last batched evaluation"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
