@@ -462,10 +462,11 @@ def test_separable_cholesky_and_eigen_formulations_agree():
         assert vec_relerr(a[1], b[1]) < 1e-7
 
 
-def test_multi_subject_batch_matches_per_subject_evaluations(ctx):
-    """BASELINE config 4 pattern: several subjects (own x, Y, own prior factors) in ONE launch sequence."""
+@pytest.mark.parametrize("N,M,B", [(96, 3, 5), (77, 3, 6), (129, 2, 11)])
+def test_multi_subject_batch_matches_per_subject_evaluations(ctx, N, M, B):
+    """BASELINE config 4 pattern: several subjects (own x, Y, own prior factors) in ONE launch sequence; odd N exercises the
+    row-pair tail of the prior solves (k_prior_trsv) and the ragged last block of the factorisation."""
     from nonstationary_multivariate_gaussian_process_amd import sim
-    N, M, B = 96, 3, 5
     subs = [sim.simulate_nonseparable(N, M, seed=s) for s in range(B)]
     hyper = sim.HYPER_SVC_MPISIM
     hv = [hyper[k] for k in SVC_KEYS]
