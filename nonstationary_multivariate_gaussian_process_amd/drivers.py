@@ -61,6 +61,60 @@ def map_nonseparable(x, Y, pars0, hyper_pars, N_opt=1000, lr=2e-1, checkpoint_pa
     return pars, hist
 
 
+def map_separable(x, Y, pars0, hyper_pars, N_opt=2000, lr=2e-1, verbose=False):
+    """MAP estimate of the separable model by Adam (``Separable_Model/Separable_model.py:147-166``): leaves
+    ``[tilde_l | tilde_sigma | uL_vec | tilde_sigma2_err]``, two parameter groups with lr 0.2 each, ``NegLog.backward()`` per
+    iteration.  Returns (pars [2N+T+1], target_value_hist [N_opt])."""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    Y = torch.as_tensor(Y, dtype=torch.float64)
+    N, M = Y.shape
+    T = M * (M + 1) // 2
+    p0 = torch.as_tensor(np.asarray(pars0, dtype=np.float64))
+    tilde_l = p0[:N].clone().requires_grad_(True)
+    tilde_sigma = p0[N:2 * N].clone().requires_grad_(True)
+    uL_vec = p0[2 * N:2 * N + T].clone().requires_grad_(True)
+    tilde_sigma2_err = p0[-1:].clone().requires_grad_(True)
+    optimizer = torch.optim.Adam([{"params": [tilde_sigma, uL_vec, tilde_sigma2_err], "lr": lr}, {"params": tilde_l, "lr": lr}])
+    hist = np.zeros(N_opt)
+    for i in range(N_opt):
+        optimizer.zero_grad()
+        Pars = torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)])
+        out = logpos.nlogpos_obj(Pars, Y, x, **hyper_pars, verbose=True)
+        out[0].backward()
+        optimizer.step()
+        hist[i] = -float(out[0].detach())
+        if verbose and i % 100 == 99:
+            print("%d/%d target %.8g" % (i + 1, N_opt, hist[i]))
+    return torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)]).detach().numpy().copy(), hist
+
+
+def map_stationary(x, Y, pars0, hyper_pars, N_opt=1000, lr=1e-1, verbose=False):
+    """MAP estimate of the stationary (LMC) model by Adam (``Stationary_Model/Stationary_model.py:112-131``): Adam(lr 0.1) over
+    ``tilde_l, uL_vec, tilde_sigma2_err``; ``tilde_sigma`` stays at its initial value ("fixed for correlation", :89).  Returns
+    (pars [T+3], target_value_hist [N_opt])."""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    Y = torch.as_tensor(Y, dtype=torch.float64)
+    M = Y.shape[1]
+    T = M * (M + 1) // 2
+    p0 = torch.as_tensor(np.asarray(pars0, dtype=np.float64))
+    tilde_l = p0[:1].clone().requires_grad_(True)
+    tilde_sigma = p0[1:2].clone()
+    uL_vec = p0[2:2 + T].clone().requires_grad_(True)
+    tilde_sigma2_err = p0[-1:].clone().requires_grad_(True)
+    optimizer = torch.optim.Adam([tilde_l, uL_vec, tilde_sigma2_err], lr=lr)
+    hist = np.zeros(N_opt)
+    for i in range(N_opt):
+        optimizer.zero_grad()
+        Pars = torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)])
+        out = logpos.nlogpos_obj_S(Pars, Y, x, **hyper_pars, verbose=True)
+        out[0].backward()
+        optimizer.step()
+        hist[i] = -float(out[0].detach())
+        if verbose:
+            print("%dth iteration with target value %.8g" % (i + 1, hist[i]))
+    return torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)]).detach().numpy().copy(), hist
+
+
 class HMCSampler:
     """Hamiltonian Monte Carlo with a (optionally dense) constant mass matrix.
 

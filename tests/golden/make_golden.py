@@ -361,6 +361,52 @@ def gen_local_estimation(only):
     save(name, **out)
 
 
+def gen_map_sep_sta(only):
+    """MAP trajectories of the separable (Separable_model.py:147-166: Adam, lr 0.2 on both groups) and stationary
+    (Stationary_model.py:112-131: Adam lr 0.1 on [tilde_l, uL_vec, tilde_sigma2_err], tilde_sigma fixed) loops."""
+    name = "map_sep_sta_N64_M3"
+    if only and not name.startswith(only):
+        return
+    N, M = 64, 3
+    T = M * (M + 1) // 2
+    x, Y = sim.rngfree_inputs(N, M)
+    steps = 60
+    # separable
+    p0 = sim.rngfree_pars_sep(N, M)
+    tl = t(p0[:N]).clone().requires_grad_(True)
+    ts = t(p0[N:2 * N]).clone().requires_grad_(True)
+    uL = t(p0[2 * N:2 * N + T]).clone().requires_grad_(True)
+    tse = t(p0[-1:]).clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [ts, uL, tse], "lr": 0.2}, {"params": tl, "lr": 0.2}])
+    hist = np.zeros(steps)
+    for i in range(steps):
+        opt.zero_grad()
+        P = torch.cat([tl, ts, uL, tse.view(1)])
+        out = logpos.nlogpos_obj(P, t(Y), t(x), **sim.HYPER_SEP, verbose=True)
+        out[0].backward()
+        opt.step()
+        hist[i] = -float(out[0].detach())
+    sep_end = torch.cat([tl, ts, uL, tse.view(1)]).detach().numpy()
+    # stationary
+    q0 = sim.rngfree_pars_sta(M)
+    tl1 = t(q0[:1]).clone().requires_grad_(True)
+    ts1 = t(q0[1:2]).clone()
+    uL1 = t(q0[2:2 + T]).clone().requires_grad_(True)
+    tse1 = t(q0[-1:]).clone().requires_grad_(True)
+    opt = torch.optim.Adam([tl1, uL1, tse1], lr=0.1)
+    hist_s = np.zeros(steps)
+    for i in range(steps):
+        opt.zero_grad()
+        P = torch.cat([tl1, ts1, uL1, tse1.view(1)])
+        out = logpos.nlogpos_obj_S(P, t(Y), t(x), **sim.HYPER_STA, verbose=True)
+        out[0].backward()
+        opt.step()
+        hist_s[i] = -float(out[0].detach())
+    sta_end = torch.cat([tl1, ts1, uL1, tse1.view(1)]).detach().numpy()
+    save(name, x=x, Y=Y, steps=steps, sep_pars0=p0, sep_hyper=hyper_vec(sim.HYPER_SEP, SEP_KEYS), sep_hist=hist, sep_end=sep_end,
+         sta_pars0=q0, sta_hyper=hyper_vec(sim.HYPER_STA, STA_KEYS), sta_hist=hist_s, sta_end=sta_end)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -376,3 +422,4 @@ if __name__ == "__main__":
     gen_sep_big(a.only)
     gen_logpdf1(a.only)
     gen_local_estimation(a.only)
+    gen_map_sep_sta(a.only)
