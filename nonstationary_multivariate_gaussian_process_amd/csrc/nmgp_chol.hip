@@ -1464,15 +1464,20 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     // phase boundaries of the critical workgroup
 #define PS_STAMP(i)                                                              \
     do {                                                                         \
-        if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)wall_clock64(); \
+        if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = (long long)wall_clock64(); \
     } while (0)
     PS_STAMP(0);
     __shared__ __attribute__((aligned(32))) double smem[PS_SMEM_DOUBLES > 4 * SY_BK * SY_LD ? PS_SMEM_DOUBLES : 4 * SY_BK * SY_LD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    if ((int)blockIdx.x >= T) {
+    // 1-D grid, role-major: workgroup id = role index * nbatch + matrix.  The dispatcher hands out workgroups in id order,
+    // so the critical workgroup 0 of EVERY matrix starts in the first round (with matrix-major order the last subjects'
+    // critical workgroups of an 8-subject batch queued behind ~270 others and started one round late), and consecutive ids
+    // -- the same role of different matrices -- land on different XCDs.
+    const int bx = (int)blockIdx.x / nbatch, by = (int)blockIdx.x - bx * nbatch;
+    if (bx >= T) {
         // ---- update role: one 128x128 tile of the delayed K = 64 update of the remaining panel columns ----
-        const int t = (int)blockIdx.x - T + (int)blockIdx.y * u_tiles;       // compact tile index over the batch
+        const int t = bx - T + by * u_tiles;       // compact tile index over the batch
         const double* Ap = Ab + (size_t)(ck - 64) * lda + (ck + 128);
         double* Cp = Ab + (size_t)(ck + 128) * lda + (ck + 128);
         syrk_tile_body<4, SY_BK>(Ap, lda, Cp, lda, u_mrows, u_ncols, 64, bstride, bstride, u_kflags, -u_tiles, nbatch, t, 0,
@@ -1480,7 +1485,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         return;
     }
     // ---- solve role ----
-    double* A = Ab + (size_t)blockIdx.y * bstride;
+    double* A = Ab + (size_t)by * bstride;
     v4d* opsC = reinterpret_cast<v4d*>(smem);                    // [4 q][4 sg][64 lanes]: -L[cb + 16 q + i][4 (4 sg + kk) + l4]
     v4d* opsT = reinterpret_cast<v4d*>(smem + 4096);             // [10][64 lanes], as in k_trsm_64f
     double* Xps = smem + PS_XPS_OFF;                             // [64][PS_XLD]: X[k+1, k-1] (workgroup 0)
@@ -1489,16 +1494,16 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     // launch) and nothing else: its waves 4..7 only take part in the barriers.  The FP64 matrix pipe of a SIMD is shared by
     // the waves on it, and the ~230 MFMAs per wave that lead up to the factorisation ARE the critical path; a second block
     // row on the same CU doubled them (measured: 12.4 us against 7).
-    const bool wg0 = blockIdx.x == 0;
+    const bool wg0 = bx == 0;
     const bool isC = wg0 && w < 4;
     // Workgroup 1, waves 0..3 ("P"): block row k + 2, the critical rows of the NEXT launch.  They bring their own diagonal
     // block (k+2, k+2) fully up to date -- column block k - 1 (its pending update, taken over from the update role, which
     // skips that 64x64 block: flag 128) AND column block k (both operands are their own rows: X[k+2, k-1], X[k+2, k]) -- so
     // that next launch's C finds only ONE pass left between its solve and the factorisation.  `pre` = block k + 2 is inside
     // the panel.
-    const bool wg1 = pre && blockIdx.x == 1;
+    const bool wg1 = pre && bx == 1;
     const bool isP = wg1 && w < 4;
-    const int row = wg0 ? ck + 64 + 16 * w + l15 : ck + 128 + 128 * ((int)blockIdx.x - 1) + 16 * w + l15;
+    const int row = wg0 ? ck + 64 + 16 * w + l15 : ck + 128 + 128 * (bx - 1) + 16 * w + l15;
     const bool rv = row < m_act && !(wg0 && w >= 4);
     const int rowc = row < m_act ? row : (m_act - 1);            // clamped: loads stay in bounds, results are masked
     // (1) issue every global load this thread needs up front
@@ -1720,7 +1725,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     }
     __syncthreads();
     PS_STAMP(6);
-    potf2b_core_mfma(P, info + (size_t)blockIdx.y * istride, ck + 64);     // (the fused schedule needs NMGP_POTF2 at its default)
+    potf2b_core_mfma(P, info + (size_t)by * istride, ck + 64);     // (the fused schedule needs NMGP_POTF2 at its default)
     PS_STAMP(7);
     potf2b_store(A + (size_t)(ck + 64) * lda + (ck + 64), lda, 64, P, tid, 512);
     PS_STAMP(8);
@@ -1818,7 +1823,7 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         const int pre = (ck + 192 <= c0 + w) ? 1 : 0;            // block (k+2, k+2) lies inside the panel: see the P waves
         if (pre) pl.kflags |= 128;                                // ... which own it: the update role skips that block
         long long* st = (g_stamps && ck / 64 < g_stamps_cap) ? g_stamps + (size_t)(ck / 64) * 16 : nullptr;
-        NMGP_LAUNCH(k_panel_step, dim3(T + pl.tiles, batch), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
+        NMGP_LAUNCH(k_panel_step, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
                     info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar, pre, st);
     }
 }
