@@ -51,6 +51,8 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "
             {"NMGP_CHOL_PANEL": "fused"}, {"NMGP_CHOL_PANEL": "rec"}, {"NMGP_CHOL_PANEL": "rl"},
             {"NMGP_CHOL_PANEL": "fused", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_PANEL": "fused", "NMGP_POTF2": "lds"},
             {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"},
+            {"NMGP_CHOL_LOOKAHEAD": "0"}, {"NMGP_LOOKAHEAD_CUS": "0", "NMGP_CHOL_NB1": "128"}, {"NMGP_PRIOR_OVERLAP": "0"},
+            {"NMGP_CHOL_GRAD_WIDE": "0"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0"}, {"NMGP_PRIOR_SOLVE": "rocblas"},
             {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"}]
 
 
