@@ -70,3 +70,28 @@ def reduce_rows(rows, num_subjects, world_size, device=None):
     table = table[table[:, 0] >= 0]
     table = table[np.argsort(table[:, 0], kind="stable")]
     return stats, table
+
+
+def map_subjects(subjects, xs, Ys, init_pars, hyper_pars, world_size, rank, N_opt=2000, lr=2e-1, device=None, make_map=None):
+    """Config-4 style job: the MAP loop for every subject, sharded over the ranks.  `subjects` = the global subject ids whose
+    data are given (xs [S, N], Ys [S, N, M], init_pars [S, P], in that order); this rank advances its share
+    (``partition``) in lock-step as ONE multi-subject batch (``drivers.BatchedMAP``; `make_map(xs, Ys, hyper, pars)` lets a
+    test substitute a CPU evaluator) and the per-subject results meet in the single reduction (``reduce_rows``).
+    Returns (pars_local [S_local, P], rows_local, stats, table)."""
+    mine = [k for k, s_id in enumerate(subjects) if s_id % world_size == rank]
+    rows = np.zeros((len(mine), ROW))
+    pars_local = np.zeros((len(mine), np.asarray(init_pars).shape[1]))
+    if mine:
+        if make_map is None:
+            from .drivers import BatchedMAP
+            make_map = lambda a, b, h, p: BatchedMAP(a, b, h, p, lr=lr)      # noqa: E731
+        bm = make_map(np.asarray(xs)[mine], np.asarray(Ys)[mine], hyper_pars, np.asarray(init_pars)[mine])
+        last = {}
+        pars_local, hist, alive = bm.run(N_opt, callback=lambda i, h, out: last.update(out=out))
+        for k, idx in enumerate(mine):
+            rows[k, 0] = subjects[idx]
+            rows[k, 1] = 1.0 if alive[k] else 0.0
+            rows[k, 2] = N_opt
+            rows[k, 3:8] = last["out"][k] if alive[k] else [math.inf, 0.0, 0.0, 0.0, 0.0]
+    stats, table = reduce_rows(rows, len(subjects), world_size, device=device)
+    return pars_local, rows, stats, table

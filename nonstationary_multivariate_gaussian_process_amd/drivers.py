@@ -115,6 +115,80 @@ def map_stationary(x, Y, pars0, hyper_pars, N_opt=1000, lr=1e-1, verbose=False):
     return torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)]).detach().numpy().copy(), hist
 
 
+class LockStepMAP:
+    """MAP by Adam for B independent subjects (or B restarts of one subject) advanced in lock-step: every iteration asks
+    ``value_and_grad(P [B, P])`` for the verbose tuples [B, 5], the gradients d NegLog / d pars [B, P] and a status [B] of ALL
+    of them at once, then applies torch.optim.Adam's update rule (default betas / eps, no weight decay) row by row -- the same
+    arithmetic, in the same order, as one ``torch.optim.Adam`` per subject, so a row reproduces :func:`map_nonseparable`.
+    A subject whose evaluation fails (status != 0) is frozen at its last parameters and reported with NegLog = inf from then
+    on (the reference wraps ``train()`` in try/except -> NegLog = inf, ``Nonseparable_model_mpisim.py:330-334``) while the
+    others go on.  Subclasses provide ``value_and_grad``."""
+
+    def __init__(self, init_pars, lr=2e-1, betas=(0.9, 0.999), eps=1e-8):
+        self.P = np.array(init_pars, dtype=np.float64, copy=True)
+        if self.P.ndim != 2:
+            raise ValueError("init_pars must be [B, P]")
+        self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        self.m = np.zeros_like(self.P)
+        self.v = np.zeros_like(self.P)
+        self.t = 0
+        self.alive = np.ones(self.P.shape[0], dtype=bool)
+
+    def value_and_grad(self, P):
+        raise NotImplementedError
+
+    def step(self):
+        out, grad, status = self.value_and_grad(self.P)
+        ok = self.alive & (np.asarray(status) == 0) & np.isfinite(out[:, 0])
+        self.alive = ok
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2_sqrt = np.sqrt(1.0 - self.b2 ** self.t)
+        g = grad[ok]
+        m = self.m[ok] * self.b1 + (1.0 - self.b1) * g            # exp_avg.lerp_(grad, 1 - beta1)
+        v = self.v[ok] * self.b2 + (1.0 - self.b2) * g * g        # exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        denom = np.sqrt(v) / bc2_sqrt + self.eps
+        self.P[ok] = self.P[ok] - (self.lr / bc1) * (m / denom)
+        self.m[ok], self.v[ok] = m, v
+        neglog = np.where(ok, out[:, 0], np.inf)
+        return neglog, out
+
+    def run(self, N_opt, callback=None):
+        """Returns (pars [B, P], target_value_hist [N_opt, B] = -NegLog per iteration, alive [B])."""
+        hist = np.zeros((N_opt, self.P.shape[0]))
+        for i in range(N_opt):
+            neglog, out = self.step()
+            hist[i] = -neglog
+            if callback is not None:
+                callback(i, hist[i], out)
+        return self.P.copy(), hist, self.alive.copy()
+
+
+class BatchedMAP(LockStepMAP):
+    """The MAP loop of ``Nonseparable_model_mpisim.py:330-348`` for ALL subjects of a rank at once: B subjects of the same size
+    (own x, Y, own GP-prior factors) form one multi-subject batch on the GPU (``nmgp_svc_batch_set_subjects``) and every Adam
+    iteration is ONE batched value+gradient launch sequence -- BASELINE config 4's per-GPU work (8 subjects x N = 1024) in the
+    caller's own loop.  ``xs`` [B, N], ``Ys`` [B, N, M], ``init_pars`` [B, N(1+T)+1]."""
+
+    def __init__(self, xs, Ys, hyper_pars, init_pars, lr=2e-1, ctx=None):
+        from . import _lib
+        super().__init__(init_pars, lr=lr)
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        Ys = np.ascontiguousarray(Ys, dtype=np.float64)
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
+        self.hyper = np.array([float(hyper_pars[k]) for k in keys])
+        self.ctx.set_data(xs[0], Ys[0])
+        self.ctx.svc_batch_alloc(xs.shape[0])
+        self.ctx.svc_batch_set_subjects(xs, Ys)
+
+    def value_and_grad(self, P):
+        self.ctx.svc_batch_set_pars(P)
+        self.ctx.svc_batch_eval(self.hyper, True, want_grad=True)
+        out, status = self.ctx.svc_batch_fetch()
+        return out, self.ctx.svc_batch_fetch_grad(), status
+
+
 class HMCSampler:
     """Hamiltonian Monte Carlo with a (optionally dense) constant mass matrix.
 
