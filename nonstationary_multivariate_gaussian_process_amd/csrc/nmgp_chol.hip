@@ -604,23 +604,6 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
     return pl;
 }
 
-void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
-                long long bstride, long long cstride, int ktri, int tri_row0, int tri_k0) {
-    if (mrows <= 0 || ncols <= 0 || K <= 0) return;
-    const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false);
-    const long long cs = cstride < 0 ? bstride : cstride;
-    void* tok = nullptr;
-    if (g_hook && g_hook->begin) {
-        // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
-        const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
-        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
-    }
-    NMGP_LAUNCH(k_syrk_lower, pl.grid, dim3(512), 0, s, A, lda, C, ldc, pl.mrows, ncols, K, bstride, cs, pl.kflags,
-                pl.swz, batch, tri_row0, tri_k0);
-    if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
-}
-
-
 __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
                                                    int goff, long long bstride, int istride) {
     __shared__ double colbuf[2][64];
@@ -1098,6 +1081,220 @@ static int g_potf2_exports_inv() {
     }
     return (g_potf2_valu || g_precise) ? 0 : 1;
 }
+
+// look-ahead schedule -> syrk_lower -> factor_panel_fused: the near update may factor the next panel's first diagonal block in
+// the same launch (k_syrk_small); armed by potrf_lower for exactly one syrk_lower call, answered through g_first_block_done
+struct FuseNext {
+    int* info = nullptr;
+    int istride = 0;
+    int goff = 0;
+};
+static thread_local FuseNext g_fuse_next;
+static thread_local int g_first_block_done = 0;
+
+// ---------------------------------------------------------------------------------------------
+// The same update on 64x64 tiles, for launches with FEW tiles on the critical path of a latency-bound factorisation (the
+// "near" update of the look-ahead schedule: the next panel's 512 columns).  One 128x128x512 tile keeps one CU's matrix pipes
+// busy for ~57 us (8 waves, two per SIMD) however small the launch, and the near update of a single 6144^2 matrix has at most
+// 176 such tiles for 256 CUs -- 70 us eleven times per factorisation, against a full-chip bound of 45 us for the first and
+// 3 us for the last.  With 64x64 tiles (4 waves of 32x32, 16 MFMAs per k-step and wave) there are four times as many
+// workgroups, each a quarter of the work.  Plain masked kernel: no extra-row tricks, any shape.
+// info != nullptr: the workgroup of tile (0, 0) -- the next panel's first diagonal block, the first to be dispatched -- goes on
+// to factor that block (potf2b_core, as k_potf2_64b would in a launch of its own: 17 us + a launch gap per panel boundary)
+// while the other tiles are still being updated.
+// ---------------------------------------------------------------------------------------------
+#define SS_LD 80
+__global__ __launch_bounds__(256) void k_syrk_small(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc,
+                                                     int mrows, int ncols, int K, long long bstride, int tiles_pm, int nbatch,
+                                                     int tri_row0, int tri_k0, int* __restrict__ info, int istride, int goff) {
+    constexpr size_t kOps = 4 * 16 * SS_LD * sizeof(double);
+    __shared__ __attribute__((aligned(16))) char smem[sizeof(Potf2Lds) > kOps ? sizeof(Potf2Lds) : kOps];
+    double (*sA)[16 * SS_LD] = reinterpret_cast<double (*)[16 * SS_LD]>(smem);
+    double (*sB)[16 * SS_LD] = reinterpret_cast<double (*)[16 * SS_LD]>(smem + 2 * 16 * SS_LD * sizeof(double));
+    // compact enumeration of the lower-trapezoid 64x64 tiles, column by column (bj = 0: gx tiles, bj = 1: gx - 1, ...)
+    const int gx = (mrows + 63) >> 6;
+    int bz = (int)blockIdx.x / tiles_pm;
+    int idx = (int)blockIdx.x - bz * tiles_pm;
+    if (bz >= nbatch) return;
+    int bj = 0;
+    while (idx >= gx - bj) {
+        idx -= gx - bj;
+        ++bj;
+    }
+    const int bi = bj + idx;
+    A += (size_t)bz * bstride;
+    C += (size_t)bz * bstride;
+    const bool diag = bi == bj;
+    const int row0 = bi * 64, col0 = bj * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // staging: thread (rp, cg): row pair rp (0..31), k-columns cg and cg + 8
+    const int rp = tid & 31, cg = tid >> 5;
+    const int ri = row0 + 2 * rp, rj = col0 + 2 * rp;
+    const int ric = clamp_row_pair(ri, mrows), rjc = clamp_row_pair(rj, mrows);
+    const bool ix = ri < mrows, iy = ri + 1 < mrows, jx = rj < mrows, jy = rj + 1 < mrows;
+    const bool ish = ix && (ric != ri), jsh = jx && (rjc != rj);
+    // two register sets: the k-panel stored to LDS at the end of step kt was requested two steps earlier (one step of 16 MFMAs
+    // per wave is shorter than an L2 round trip when a CU holds a single workgroup)
+    double2 ra[2][2], rb[2][2];
+    auto gload = [&](double2 (&xa)[2], double2 (&xb)[2], int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kc = k0 + cg + 8 * q;
+            const double* colp = A + (size_t)(kc < K ? kc : K - 1) * lda;
+            xa[q] = *reinterpret_cast<const double2*>(colp + ric);
+            if (!diag) xb[q] = *reinterpret_cast<const double2*>(colp + rjc);
+        }
+    };
+    auto sstore = [&](const double2 (&xa)[2], const double2 (&xb)[2], int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kl = cg + 8 * q;
+            const bool kin = (k0 + kl) < K;
+            double2 va, vb;
+            va.x = (kin && ix) ? (ish ? xa[q].y : xa[q].x) : 0.0;
+            va.y = (kin && iy) ? xa[q].y : 0.0;
+            *reinterpret_cast<double2*>(&sA[buf][kl * SS_LD + 2 * rp]) = va;
+            if (!diag) {
+                vb.x = (kin && jx) ? (jsh ? xb[q].y : xb[q].x) : 0.0;
+                vb.y = (kin && jy) ? xb[q].y : 0.0;
+                *reinterpret_cast<double2*>(&sB[buf][kl * SS_LD + 2 * rp]) = vb;
+            }
+        }
+    };
+    const bool active = !(diag && (wi * 32 + 31 < wj * 32));
+    const int nk = (K + 15) / 16;
+    int kt0 = 0;                                  // leading all-zero k-panels of triangular rows (see syrk_tile_body)
+    if (row0 >= tri_row0 && row0 - tri_row0 - tri_k0 > 0) kt0 = (row0 - tri_row0 - tri_k0) / 16;
+    if (kt0 > nk - 1) kt0 = nk - 1;
+    gload(ra[0], rb[0], kt0 * 16);
+    gload(ra[1], rb[1], (kt0 + 1) * 16);
+    // acc[tj][ti][r]: C element (i, j), i = row0 + 32 wi + 16 ti + l15, j = col0 + 32 wj + 16 tj + l4 + 4 r
+    v4d acc[2][2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row0 + wi * 32 + ti * 16 + l15;
+                const int j = col0 + wj * 32 + tj * 16 + l4 + 4 * r;
+                acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
+            }
+    sstore(ra[0], rb[0], 0, kt0 * 16);
+    gload(ra[0], rb[0], (kt0 + 2) * 16);
+    __syncthreads();
+    auto compute = [&](int cur) {
+        if (!active) return;
+        const double* tA = sA[cur] + wi * 32 + l15 + l4 * SS_LD;
+        const double* tB = (diag ? sA[cur] : sB[cur]) + wj * 32 + l15 + l4 * SS_LD;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double fa0 = tA[kk * 4 * SS_LD], fa1 = tA[kk * 4 * SS_LD + 16];
+            const double fb0 = -tB[kk * 4 * SS_LD], fb1 = -tB[kk * 4 * SS_LD + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0, fa1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1, fa1, acc[1][1], 0, 0, 0);
+        }
+    };
+    // step kt (buffer parity = (kt - kt0) & 1): multiply from the current buffer, store panel kt + 1 (register set of the
+    // opposite parity) into the other one, re-use that register set for panel kt + 3
+    for (int kt = kt0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) {
+            sstore(ra[1], rb[1], 1, (kt + 1) * 16);
+            if (kt + 3 < nk) gload(ra[1], rb[1], (kt + 3) * 16);
+        }
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        compute(1);
+        if (kt + 2 < nk) {
+            sstore(ra[0], rb[0], 0, (kt + 2) * 16);
+            if (kt + 4 < nk) gload(ra[0], rb[0], (kt + 4) * 16);
+        }
+        __syncthreads();
+    }
+    if (info != nullptr && bi == 0 && bj == 0) {
+        // the k-loop ended on a barrier: the operand buffers are free, the block moves from the accumulators into P.S
+        Potf2Lds& P = *reinterpret_cast<Potf2Lds*>(smem);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = tid + 256 * k;
+            const int r = idx & 63, c = idx >> 6;
+            if (c > r) P.S[c * PB_LD + r] = 0.0;
+        }
+        if (active) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = wi * 32 + ti * 16 + l15;
+                        const int j = wj * 32 + tj * 16 + l4 + 4 * r;
+                        if (i >= j) P.S[j * PB_LD + i] = acc[tj][ti][r];
+                    }
+        }
+        __syncthreads();
+        potf2b_core(P, info + (size_t)bz * istride, goff, 2);
+        potf2b_store(C, ldc, 64, P, tid, 256);
+        return;
+    }
+    if (active) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = row0 + wi * 32 + ti * 16 + l15;
+                    const int j = col0 + wj * 32 + tj * 16 + l4 + 4 * r;
+                    if (i < mrows && j < ncols && i >= j) C[(size_t)j * ldc + i] = acc[tj][ti][r];
+                }
+    }
+}
+
+void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
+                long long bstride, long long cstride, int ktri, int tri_row0, int tri_k0) {
+    if (mrows <= 0 || ncols <= 0 || K <= 0) return;
+    const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false);
+    const long long cs = cstride < 0 ? bstride : cstride;
+    // few 128x128 tiles (at most one per CU) and a k-loop long enough to matter: 64x64 tiles (k_syrk_small)
+    const FuseNext fuse = g_fuse_next;
+    g_fuse_next.info = nullptr;
+    static const int small_max = [] {
+        const char* e = std::getenv("NMGP_SYRK_SMALL_MAX");
+        return e ? std::atoi(e) : 256;
+    }();
+    if (!ktri && K >= 128 && (long long)pl.tiles * batch <= small_max && cs == bstride && (lda & 1) == 0 && mrows >= 2) {
+        const int gx = (mrows + 63) / 64, gy = (ncols + 63) / 64;
+        int tiles = 0;
+        for (int bj = 0; bj < gy; ++bj) tiles += gx - bj > 0 ? gx - bj : 0;
+        void* tk = nullptr;
+        if (g_hook && g_hook->begin) {
+            const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
+            tk = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
+        }
+        const bool fz = fuse.info != nullptr && mrows >= 64 && ncols >= 64;
+        NMGP_LAUNCH(k_syrk_small, dim3((unsigned)(tiles * batch)), dim3(256), 0, s, A, lda, C, ldc, mrows, ncols, K, bstride, tiles,
+                    batch, tri_row0, tri_k0, fz ? fuse.info : (int*)nullptr, fuse.istride, fuse.goff);
+        if (fz) g_first_block_done = 1;
+        if (tk && g_hook->end) g_hook->end(g_hook->user, tk);
+        return;
+    }
+    void* tok = nullptr;
+    if (g_hook && g_hook->begin) {
+        // algorithmic flop of this launch: 2 K per element (i >= j) of the mrows x ncols lower trapezoid
+        const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
+        tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
+    }
+    NMGP_LAUNCH(k_syrk_lower, pl.grid, dim3(512), 0, s, A, lda, C, ldc, pl.mrows, ncols, K, bstride, cs, pl.kflags,
+                pl.swz, batch, tri_row0, tri_k0);
+    if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // panel solve  X L^T = A  (L: nb x nb lower, nb <= 64; A: rows x nb, overwritten by X)
@@ -1808,7 +2005,9 @@ static const char* g_stamps_path = nullptr;
 
 static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                                int batch, long long bs, int is) {
-    potf2_64(s, A + (size_t)c0 * lda + c0, lda, 64, info, c0, batch, bs, is);      // the panel's first diagonal block
+    if (!g_first_block_done)                                                       // the panel's first diagonal block
+        potf2_64(s, A + (size_t)c0 * lda + c0, lda, 64, info, c0, batch, bs, is);  // (unless the near update factored it)
+    g_first_block_done = 0;
     const int nk = w / 64;
     for (int k = 0; k < nk; ++k) {
         const int ck = c0 + 64 * k;
@@ -1834,20 +2033,29 @@ static int g_fused_max_batch = -1; // NMGP_CHOL_FUSED_MAX_BATCH: largest batch t
                                    // batch * n <= 73728 (measured: n = 6144: 8 chains 523 vs 503 evals/s, 16 chains 418 vs 616;
                                    // n = 3072: 16 subjects 3211 vs 2729, 24 subjects 3563, 32 subjects 2877 vs 3714)
 
+static const int g_fuse_potf2 = [] {   // NMGP_CHOL_FUSE_POTF2=0: the next panel's first block in a launch of its own (A/B)
+    const char* e = std::getenv("NMGP_CHOL_FUSE_POTF2");
+    return e ? std::atoi(e) : 1;
+}();
+
+static bool panel_takes_fused_steps(int n, int w, int lda, int batch) {
+    if (g_panel_mode < 0) {
+        const char* e = std::getenv("NMGP_CHOL_PANEL");
+        g_panel_mode = !e ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : (std::strcmp(e, "rec") == 0 ? 2 : (std::strcmp(e, "rl") == 0 ? 3 : 0)));
+        if (const char* m = std::getenv("NMGP_CHOL_FUSED_MAX_BATCH")) g_fused_max_batch = std::atoi(m);
+    }
+    const bool can_fuse = w > 0 && (w % 64 == 0) && g_potf2_exports_inv() && g_potf2_xbar == 2 && (lda % 2 == 0);
+    const bool small = g_fused_max_batch >= 0 ? batch <= g_fused_max_batch : (long long)batch * n <= 73728;
+    return can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && small));
+}
+
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
     static const int rec_min_batch = [] {       // NMGP_CHOL_REC_MIN_BATCH: smallest batch that takes the recursive panels
         const char* e = std::getenv("NMGP_CHOL_REC_MIN_BATCH");
         return e ? std::atoi(e) : 4;
     }();
-    if (g_panel_mode < 0) {
-        const char* e = std::getenv("NMGP_CHOL_PANEL");
-        g_panel_mode = !e ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : (std::strcmp(e, "rec") == 0 ? 2 : (std::strcmp(e, "rl") == 0 ? 3 : 0)));
-        if (const char* m = std::getenv("NMGP_CHOL_FUSED_MAX_BATCH")) g_fused_max_batch = std::atoi(m);
-    }
-    const bool can_fuse = (w % 64 == 0) && g_potf2_exports_inv() && g_potf2_xbar == 2 && (lda % 2 == 0);
-    const bool small = g_fused_max_batch >= 0 ? batch <= g_fused_max_batch : (long long)batch * n <= 73728;
-    if (can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && small)))
+    if (panel_takes_fused_steps(n, w, lda, batch))
         factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
@@ -1952,8 +2160,14 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         // the previous far update also wrote the next panel's columns
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
         const int mact = active_rows(n, extra, xtri, c1);
+        if (g_fuse_potf2 && panel_takes_fused_steps(n, w1n, lda, batch)) {
+            g_fuse_next.info = info;
+            g_fuse_next.istride = is;
+            g_fuse_next.goff = c1;
+        }
         syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, mact - c1, w1n, w1, batch, bs, -1,
                    0, xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
+        g_fuse_next.info = nullptr;
         // the far update starts only when the NEAR one is through: started together they share the chip and the near
         // update -- which the next panel waits for -- takes 2-4x as long (96-227 us instead of ~45 in the kernel trace)
         hipEventRecord(evPanel, s);

@@ -321,7 +321,7 @@ def test_prediction_against_reference_golden(ctx):
 # ---------------------------------------------------------------------------------------------------
 # custom blocked Cholesky (nmgp_chol.hip): FP64-MFMA SYRK, 64-wide panel steps, right-hand side as an extra row
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 17, 63, 64, 65, 127, 130, 257, 513, 600, 1000, 1537])
+@pytest.mark.parametrize("n", [1, 2, 17, 63, 64, 65, 127, 130, 257, 513, 600, 1000, 1537, 1600, 2112])
 def test_custom_cholesky_against_lapack(ctx, n):
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n + 3))
@@ -340,14 +340,18 @@ def test_custom_cholesky_against_lapack(ctx, n):
     assert np.array_equal(L2, ctx.cholesky(A, rhs, algo=1)[0])
 
 
-def test_custom_cholesky_reports_indefinite_matrix(ctx):
+# (n, bad pivot): inside the first panel; the first block of the second panel (factored inside the look-ahead's near update);
+# a later block of the second panel (fused panel step); the ragged last panel
+@pytest.mark.parametrize("n,bad", [(200, 150), (1200, 520), (1200, 700), (1200, 1100)])
+def test_custom_cholesky_reports_indefinite_matrix(ctx, n, bad):
     from nonstationary_multivariate_gaussian_process_amd import _lib
-    n = 200
-    A = np.eye(n)
-    A[150, 150] = -1.0
+    rng = np.random.default_rng(n + bad)
+    G = rng.standard_normal((n, 8)) / np.sqrt(n)
+    A = np.eye(n) + G @ G.T
+    A[bad, bad] = -1.0
     with pytest.raises(_lib.NmgpNumericalError) as e:
         ctx.cholesky(A, None, algo=1)
-    assert e.value.code == 151          # LAPACK convention: leading minor 151 is not positive definite
+    assert e.value.code == bad + 1      # LAPACK convention: leading minor bad + 1 is not positive definite
 
 
 def test_rocsolver_and_custom_factorisation_agree_on_the_objective():

@@ -41,7 +41,12 @@ ctx.svc_batch_set_pars(allp2)
 ctx.svc_batch_eval(hv, True, want_grad=True)
 bout2, status2 = ctx.svc_batch_fetch()
 bgrad2 = ctx.svc_batch_fetch_grad()
-print(json.dumps({"out": list(map(float, out)), "grad": list(map(float, grad)), "batch": bout.tolist(),
+# a third subject with more than two 512-wide panels (n = 1200 = 512 + 512 + 176): the look-ahead schedule, its near update on
+# 64x64 tiles with the next panel's first block factored in the same launch, and a ragged last panel that takes neither
+d3 = sim.simulate_nonseparable(400, 3, seed=9)
+ctx.set_data(d3["x"], d3["Y"])
+out3, grad3 = ctx.logpos_svc(sim.perturb(d3["pars_true"], 0.05, 0.2), hv, prior=True, want_grad=True)
+print(json.dumps({"out3": list(map(float, out3)), "grad3": list(map(float, grad3)), "out": list(map(float, out)), "grad": list(map(float, grad)), "batch": bout.tolist(),
                   "status": status.tolist() + status2.tolist(), "out2": list(map(float, out2)),
                   "grad2": list(map(float, grad2)), "batch2": bout2.tolist(), "bgrad2": bgrad2.tolist()}))
 """
@@ -53,6 +58,7 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "
             {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"},
             {"NMGP_CHOL_LOOKAHEAD": "0"}, {"NMGP_LOOKAHEAD_CUS": "0", "NMGP_CHOL_NB1": "128"}, {"NMGP_PRIOR_OVERLAP": "0"},
             {"NMGP_CHOL_GRAD_WIDE": "0"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0"}, {"NMGP_PRIOR_SOLVE": "rocblas"},
+            {"NMGP_CHOL_FUSE_POTF2": "0"}, {"NMGP_SYRK_SMALL_MAX": "0"}, {"NMGP_SYRK_SMALL_MAX": "100000"},
             {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"}]
 
 
@@ -83,6 +89,9 @@ def test_kernel_variants_agree_with_the_default_configuration():
         assert vec_relerr(np.array(r["grad2"]), np.array(ref["grad2"])) < 1e-7, env_extra
         assert relerr(np.array(r["batch2"]), np.array(ref["batch2"])) < 1e-7, env_extra
         assert vec_relerr(np.array(r["bgrad2"]), np.array(ref["bgrad2"])) < 1e-7, env_extra
+        assert relerr(r["out3"][1], ref["out3"][1]) < 1e-11, (env_extra, r["out3"], ref["out3"])
+        assert relerr(np.array(r["out3"]), np.array(ref["out3"])) < 1e-7, env_extra
+        assert vec_relerr(np.array(r["grad3"]), np.array(ref["grad3"])) < 1e-7, env_extra
 
 
 def test_parity_suite_passes_with_nan_poisoned_device_buffers():
