@@ -1268,7 +1268,8 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         const char* e = std::getenv("NMGP_SYRK_SMALL_MAX");
         return e ? std::atoi(e) : 256;
     }();
-    if (!ktri && K >= 128 && (long long)pl.tiles * batch <= small_max && cs == bstride && (lda & 1) == 0 && mrows >= 2) {
+    // (latency regime only: the throughput batches keep one update kernel, whose launches the profiling tools replay)
+    if (!ktri && K >= 128 && batch <= 16 && (long long)pl.tiles * batch <= small_max && cs == bstride && (lda & 1) == 0 && mrows >= 2) {
         const int gx = (mrows + 63) / 64, gy = (ncols + 63) / 64;
         int tiles = 0;
         for (int bj = 0; bj < gy; ++bj) tiles += gx - bj > 0 ? gx - bj : 0;
