@@ -228,7 +228,7 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
         // is running, and uses the whole chip when none is.  NMGP_LOOKAHEAD_CUS=<n> (default 64; 0 = plain stream).
         int lo = 0, hi = 0;     // "greatest" (numerically lowest) priority is hi
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const bool prio = std::getenv("NMGP_NO_STREAM_PRIORITY") == nullptr && lo != hi;
+        const bool prio = lo != hi;
         if (prio) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
         else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         int la_cus = 64;

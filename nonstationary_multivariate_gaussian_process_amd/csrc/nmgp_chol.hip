@@ -343,7 +343,6 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     // there instead of multiplying zeros (with 1024-wide panels that was 12 % of the update flop, with 2048-wide ones 25 %)
     // (bx, by, bz0) = the launch's blockIdx, or the tile a fused kernel assigns to this workgroup; sAb / sBb: 2 * BK * SY_LD
     // doubles of LDS each
-    const bool nohalf = (ktri & 2) != 0;      // NMGP_SYRK_HALF=0: half-width tiles stay on the generic path (A/B switch)
     const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
     const bool skipq = (ktri & 128) != 0;     // the leading 64x64 block of tile (0, 0) belongs to somebody else (k_panel_step)
     const int yrow = nyr ? mrows : -1;
@@ -416,7 +415,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         // (32-bit byte offsets into the panel: (K + 16) * lda * 8 must stay below 2^31)
         // (a tile that is full in rows and 64 columns wide -- the K = 64 updates inside a panel -- also qualifies)
         const int ncw = ncols - col0 >= SY_BM ? SY_BM : ncols - col0;
-        if (row0 + SY_BM <= mrows && (ncw == SY_BM || (ncw == 64 && !nohalf)) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
+        if (row0 + SY_BM <= mrows && (ncw == SY_BM || ncw == 64) && col0 + SY_BM <= mrows && (K & 31) == 0 &&
             (long long)(K + 16) * lda * 8 < 0x7fff0000LL) {
             int kt0f = ktri ? row0 / BK : 0;
             if (row0 >= tri_row0) {
@@ -551,8 +550,6 @@ __global__ __launch_bounds__(512, 4) void k_syrk_lower(const double* __restrict_
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
 static int g_syrk_env = 0;     // 0 = environment not read yet
-static int g_syrk_swz = 1;     // NMGP_SYRK_SWIZZLE=0 disables the XCD-aware tile order
-static int g_syrk_half = 1;    // NMGP_SYRK_HALF=0: see syrk_tile_body
 static int g_syrk_yrow = 1;    // NMGP_SYRK_YROW=0: the right-hand-side row keeps its own (masked) tile row
 
 // launch geometry of one trapezoid update: grid, tile-order mode and kernel flags (shared with the fused panel step)
@@ -567,8 +564,6 @@ struct SyrkPlan {
 static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int batch, int ktri, bool compact_only) {
     if (!g_syrk_env) {
         g_syrk_env = 1;
-        if (const char* z = std::getenv("NMGP_SYRK_SWIZZLE")) g_syrk_swz = std::atoi(z) != 0;
-        if (const char* z = std::getenv("NMGP_SYRK_HALF")) g_syrk_half = std::atoi(z) != 0;
         if (const char* z = std::getenv("NMGP_SYRK_YROW")) g_syrk_yrow = std::atoi(z) != 0;
     }
     SyrkPlan pl;
@@ -589,7 +584,7 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
         const int W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
         pl.tiles += W * (W + 1) / 2 + (gx - c0 - W) * W;
     }
-    if (compact_only || (g_syrk_swz && gy >= 2)) {
+    if (compact_only || gy >= 2) {
         const long long total = (long long)pl.tiles * batch;
         const long long rounds = (total + 511) / 512;   // 8 XCDs x 64 tiles per round
         if (rounds >= 16 && !compact_only) {            // chunks of 64 tiles per XCD (L2 reuse)
@@ -600,7 +595,7 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
             pl.swz = -pl.tiles;
         }
     }
-    pl.kflags = (ktri ? 1 : 0) | (g_syrk_half ? 0 : 2) | yflag;
+    pl.kflags = (ktri ? 1 : 0) | yflag;
     return pl;
 }
 
@@ -829,7 +824,7 @@ struct Potf2Lds {
 // Factor the 64x64 block held in P.S (lower triangle valid, strict upper zero).  Called by EVERY thread of the workgroup
 // (the barriers are workgroup barriers); threads 0..255 do the work, any further waves only take part in the barriers.
 // On return (after the trailing barrier) P.S holds L and P.Einv the inverted diagonal 16x16 blocks.
-// The matrix-core flavour of the whole 64x64 factorisation (xbar == 2).  Wave 0 runs the critical chain WITHOUT waiting for
+// The whole 64x64 factorisation on the matrix cores.  Wave 0 runs the critical chain WITHOUT waiting for
 // the others: after the 16x16 diagonal block q (potf2m_group x 4) and ONE barrier that publishes L_qq and inv(L_qq), it solves
 // block row q + 1 itself (4 MFMAs), updates the next diagonal tile (4 MFMAs) -- which never leaves its registers -- and goes
 // straight on to the next block.  Waves 1 and 2 bring the rows below up to date meanwhile (row q + 1 + w: X_i, the X_j it needs
@@ -914,112 +909,6 @@ __device__ __forceinline__ void potf2b_core_mfma(Potf2Lds& P, int* __restrict__ 
     __syncthreads();
 }
 
-__device__ __forceinline__ void potf2b_core(Potf2Lds& P, int* __restrict__ info, int goff, int xbar) {
-    if (xbar == 2) {
-        potf2b_core_mfma(P, info, goff);
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        if (w == 0 && xbar) {
-            // (A), register / crossbar flavour: thread (r, g) = (lane >> 2, lane & 3)
-            const int r = lane >> 2, g = lane & 3;
-            double a[4], e[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cc = 4 * kk + g;
-                a[kk] = (cc <= r) ? P.S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
-                e[kk] = (cc == r) ? 1.0 : 0.0;
-            }
-            double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
-            potf2x_steps4<0>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<1>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<2>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2x_steps4<3>(a, e, P.pivs, Sqq, q, info, goff, r, g, lane);
-            __builtin_amdgcn_wave_barrier();
-            const double sr = rsqrt(P.pivs[16 * q + r]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cc = 4 * kk + g;
-                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(P.pivs[16 * q + cc]);
-                P.Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
-            }
-        } else if (w == 0) {
-            // (A) thread (r, g) = (lane & 15, lane >> 4) keeps S_qq[r][4 kk + g] and E[r][4 kk + g], kk = 0..3
-            const int r = l15, g = l4;
-            double a[4], e[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cc = 4 * kk + g;
-                a[kk] = (cc <= r) ? P.S[(16 * q + cc) * PB_LD + 16 * q + r] : 0.0;
-                e[kk] = (cc == r) ? 1.0 : 0.0;
-            }
-            if (g == 0) P.colbuf[0][r] = a[0];
-            if (r == 0) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) P.rowbuf[0][4 * kk + g] = e[kk];
-            }
-            __builtin_amdgcn_wave_barrier();
-            double* Sqq = &P.S[(16 * q) * PB_LD + 16 * q];
-            potf2b_steps4<0>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<1>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<2>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
-            potf2b_steps4<3>(a, e, P.colbuf, P.rowbuf, P.pivs, Sqq, q, info, goff, r, g, lane);
-            // L_qq = S~ D^-1/2 (column scaling of the unscaled columns the steps left in S), inv(L_qq) = D^-1/2 E (rows)
-            const double sr = rsqrt(P.pivs[16 * q + r]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cc = 4 * kk + g;
-                if (cc <= r) Sqq[cc * PB_LD + r] *= rsqrt(P.pivs[16 * q + cc]);
-                P.Einv[q][r][cc] = (cc <= r) ? sr * e[kk] : 0.0;
-            }
-        }
-        __syncthreads();
-        if (q == 3) break;
-        // (B) X_i = S_iq inv(L_qq)^T, row block i = q + 1 + w
-        {
-            const int i = q + 1 + w;
-            if (i < 4) {
-                v4d x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double av = P.Einv[q][l15][4 * kk + l4];                                   // A: row c' = l15, k = c
-                    const double bv = P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];            // B: k = c, col = row r
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
-                }
-                // all four k-slices are read before any of them is overwritten (same wave, in order)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) P.S[(16 * q + l4 + 4 * reg) * PB_LD + 16 * i + l15] = x[reg];
-            }
-        }
-        __syncthreads();
-        // (C) S_ij -= X_i X_j^T for q < j <= i <= 3; tile t of this step goes to wave t % 4
-        {
-            int t = 0;
-            for (int i = q + 1; i < 4; ++i)
-                for (int j = q + 1; j <= i; ++j, ++t) {
-                    if ((t & 3) != w) continue;
-                    v4d acc;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[reg] = P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double av = -P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * j + l15];      // A: row of X_j
-                        const double bv = P.S[(16 * q + 4 * kk + l4) * PB_LD + 16 * i + l15];       // B: row of X_i
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) P.S[(16 * j + l4 + 4 * reg) * PB_LD + 16 * i + l15] = acc[reg];
-                }
-        }
-        __syncthreads();
-    }
-}
-
-// L goes to the lower triangle of the 64x64 block at A; the STRICT UPPER part of each diagonal 16x16 block (never read by
-// a lower-triangular consumer) receives inv(L_qq) transposed, which the panel solves pick up instead of inverting again
 __device__ __forceinline__ void potf2b_store(double* __restrict__ A, int lda, int nb, const Potf2Lds& P, int tid, int nthreads) {
     for (int idx = tid; idx < 4096; idx += nthreads) {
         const int r = idx & 63, c = idx >> 6;
@@ -1031,7 +920,7 @@ __device__ __forceinline__ void potf2b_store(double* __restrict__ A, int lda, in
 }
 
 __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
-                                                    int goff, long long bstride, int istride, int xbar) {
+                                                    int goff, long long bstride, int istride) {
     A += (size_t)blockIdx.x * bstride;
     info += (size_t)blockIdx.x * istride;
     __shared__ Potf2Lds P;
@@ -1045,39 +934,31 @@ __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int l
         P.S[c * PB_LD + r] = v;
     }
     __syncthreads();
-    potf2b_core(P, info, goff, xbar);
+    potf2b_core_mfma(P, info, goff);
     potf2b_store(A, lda, nb, P, tid, 256);
 }
 
 static int g_potf2_valu = -1;     // NMGP_POTF2=valu selects the unblocked kernel (k_potf2_64)
-static int g_potf2_xbar = 2;      // phase (A) of k_potf2_64b: 2 = 4-column groups on the matrix cores (default), 1 = pivot steps
-                                  // over DPP / bpermute (NMGP_POTF2=xbar), 0 = pivot steps through an LDS column (NMGP_POTF2=lds)
 // set by potrf_lower(precise = 1): substitution-based panel kernels (no inverted 16x16 blocks) for the ill-conditioned,
 // cached prior covariances (RBF + 1e-6 I, condition number up to 1e11), where the inverse-based solves cost parity digits
 static thread_local int g_precise = 0;
-static const int g_nb1_grad_wide = [] {      // NMGP_CHOL_GRAD_WIDE=0: 1024-wide panels when the L^-T rows ride along (A/B; with the
-    const char* e = std::getenv("NMGP_CHOL_GRAD_WIDE");   // zero k-panels of those rows skipped 2048 wins: 234.6 vs 233.6 at 64 chains)
-    return e ? std::atoi(e) : 1;
-}();
 
 void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, int batch, long long bstride,
               int istride) {
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
-        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : ((e && std::strcmp(e, "xbar") == 0) ? 1 : 2);
     }
     if (g_potf2_valu || g_precise)
         NMGP_LAUNCH(k_potf2_64, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
     else
-        NMGP_LAUNCH(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride, g_potf2_xbar);
+        NMGP_LAUNCH(k_potf2_64b, dim3(batch), dim3(256), 0, s, A, lda, nb, info, goff, bstride, istride);
 }
 
 static int g_potf2_exports_inv() {
     if (g_potf2_valu < 0) {
         const char* e = std::getenv("NMGP_POTF2");
         g_potf2_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
-        g_potf2_xbar = (e && std::strcmp(e, "lds") == 0) ? 0 : ((e && std::strcmp(e, "xbar") == 0) ? 1 : 2);
     }
     return (g_potf2_valu || g_precise) ? 0 : 1;
 }
@@ -1238,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_syrk_small(const double* __restrict__ A
                     }
         }
         __syncthreads();
-        potf2b_core(P, info + (size_t)bz * istride, goff, 2);
+        potf2b_core_mfma(P, info + (size_t)bz * istride, goff);
         potf2b_store(C, ldc, 64, P, tid, 256);
         return;
     }
@@ -1601,7 +1482,6 @@ __global__ __launch_bounds__(256, 4) void k_trsm_64f(const double* __restrict__ 
 }
 
 static int g_trsm_valu = -1;     // NMGP_TRSM=valu selects the substitution kernel (k_trsm_64)
-static int g_trsm_slow = 0;      // NMGP_TRSM=staged keeps full blocks on the general matrix-core kernel (k_trsm_64m)
 static int g_potf2_exports_inv();  // 1 when the block factorisation in use leaves inv(L_qq) in the diagonal blocks
 
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
@@ -1610,11 +1490,10 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
     if (g_trsm_valu < 0) {
         const char* e = std::getenv("NMGP_TRSM");
         g_trsm_valu = (e && std::strcmp(e, "valu") == 0) ? 1 : 0;
-        g_trsm_slow = (e && std::strcmp(e, "staged") == 0) ? 1 : 0;
     }
     if (g_trsm_valu || g_precise) {
         NMGP_LAUNCH(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
-    } else if (nb == 64 && g_potf2_exports_inv() && !g_trsm_slow) {
+    } else if (nb == 64 && g_potf2_exports_inv()) {
         NMGP_LAUNCH(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
     } else {
         // groups of 128 rows per workgroup: more of them amortise the factor preparation once the launch would fill the
@@ -1656,7 +1535,7 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
-                                                        int u_tiles, int nbatch, int xbar, int pre,
+                                                        int u_tiles, int nbatch, int pre,
                                                         long long* __restrict__ stamps) {
     // developer aid (NMGP_STEP_STAMPS=<file>): thread 0 of workgroup 0 of matrix 0 records the 100 MHz wall clock at the
     // phase boundaries of the critical workgroup
@@ -2024,7 +1903,7 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         if (pre) pl.kflags |= 128;                                // ... which own it: the update role skips that block
         long long* st = (g_stamps && ck / 64 < g_stamps_cap) ? g_stamps + (size_t)(ck / 64) * 16 : nullptr;
         NMGP_LAUNCH(k_panel_step, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
-                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, g_potf2_xbar, pre, st);
+                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, st);
     }
 }
 
@@ -2045,17 +1924,14 @@ static bool panel_takes_fused_steps(int n, int w, int lda, int batch) {
         g_panel_mode = !e ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : (std::strcmp(e, "rec") == 0 ? 2 : (std::strcmp(e, "rl") == 0 ? 3 : 0)));
         if (const char* m = std::getenv("NMGP_CHOL_FUSED_MAX_BATCH")) g_fused_max_batch = std::atoi(m);
     }
-    const bool can_fuse = w > 0 && (w % 64 == 0) && g_potf2_exports_inv() && g_potf2_xbar == 2 && (lda % 2 == 0);
+    const bool can_fuse = w > 0 && (w % 64 == 0) && g_potf2_exports_inv() && (lda % 2 == 0);
     const bool small = g_fused_max_batch >= 0 ? batch <= g_fused_max_batch : (long long)batch * n <= 73728;
     return can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && small));
 }
 
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
-    static const int rec_min_batch = [] {       // NMGP_CHOL_REC_MIN_BATCH: smallest batch that takes the recursive panels
-        const char* e = std::getenv("NMGP_CHOL_REC_MIN_BATCH");
-        return e ? std::atoi(e) : 4;
-    }();
+    const int rec_min_batch = 4;                 // smallest batch that takes the recursive panels
     if (panel_takes_fused_steps(n, w, lda, batch))
         factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
@@ -2119,9 +1995,10 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     } ps(precise);
     // auto panel width (512 / 1024 / 2048; 64 chains of n = 6144: 673 / 716 / 728 evals/s): a wider panel halves the passes over the trailing matrix (each tile's C load / store and launch tail) and
     // pays with one more K = 512 level inside the panel; +1.5 % for 32 chains of n = 6144, +2 % for 64 subjects of
-    // n = 3072, slower for one chain or 8 subjects; 2048 loses 3 % when the L^-T rows ride along (gradient)
+    // n = 3072, slower for one chain or 8 subjects; with the L^-T rows (gradient) 2048 wins since their zero k-panels are skipped
+    // (234.6 against 233.6 evals/s at 64 chains)
     if (nb1 <= 0)
-        nb1 = (batch >= 16 && n >= 6144 && (xtri == 0 || g_nb1_grad_wide)) ? 2048
+        nb1 = (batch >= 16 && n >= 6144) ? 2048
               : (((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) && (long long)batch * n > 73728) ? 1024 : 512;
     // (batches small enough for the fused panel steps keep 512: separable N = 4096, D = 5: 4.39 ms against 4.55 with 1024)
     const int is = istride;

@@ -51,13 +51,13 @@ print(json.dumps({"out3": list(map(float, out3)), "grad3": list(map(float, grad3
                   "grad2": list(map(float, grad2)), "batch2": bout2.tolist(), "bgrad2": bgrad2.tolist()}))
 """
 
-VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "staged"}, {"NMGP_POTF2": "valu"}, {"NMGP_POTF2": "lds"}, {"NMGP_POTF2": "xbar"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
-            {"NMGP_SYRK_YROW": "0"}, {"NMGP_SYRK_HALF": "0"}, {"NMGP_SYRK_SWIZZLE": "0"},
+VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
+            {"NMGP_SYRK_YROW": "0"},
             {"NMGP_CHOL_PANEL": "fused"}, {"NMGP_CHOL_PANEL": "rec"}, {"NMGP_CHOL_PANEL": "rl"},
-            {"NMGP_CHOL_PANEL": "fused", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_PANEL": "fused", "NMGP_POTF2": "lds"},
+            {"NMGP_CHOL_PANEL": "fused", "NMGP_CHOL_NB1": "128"},
             {"NMGP_CHOL_LOOKAHEAD": "1", "NMGP_CHOL_NB1": "128"}, {"NMGP_CHOL_NB1": "256"},
             {"NMGP_CHOL_LOOKAHEAD": "0"}, {"NMGP_LOOKAHEAD_CUS": "0", "NMGP_CHOL_NB1": "128"}, {"NMGP_PRIOR_OVERLAP": "0"},
-            {"NMGP_CHOL_GRAD_WIDE": "0"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0"}, {"NMGP_PRIOR_SOLVE": "rocblas"},
+            {"NMGP_CHOL_FUSED_MAX_BATCH": "0"}, {"NMGP_PRIOR_SOLVE": "rocblas"},
             {"NMGP_CHOL_FUSE_POTF2": "0"}, {"NMGP_SYRK_SMALL_MAX": "0"}, {"NMGP_SYRK_SMALL_MAX": "100000"},
             {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"}]
 
