@@ -104,3 +104,21 @@ def test_parity_suite_passes_with_nan_poisoned_device_buffers():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
                           "-x", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("env_extra", [
+    {"NMGP_SYRK_SMALL_MAX": "100000", "NMGP_CHOL_NB1": "128"},      # every K >= 128 update on 64x64 tiles, look-ahead from n > 256
+    {"NMGP_SYRK_SMALL_MAX": "100000", "NMGP_CHOL_NB1": "192", "NMGP_CHOL_PANEL": "rl"},   # panels that are no multiple of 128
+    {"NMGP_CHOL_NB1": "64"},                                        # one step per panel: every update is a trailing update
+])
+def test_factorisation_suite_under_small_tile_and_narrow_panel_settings(env_extra):
+    """The LAPACK comparisons of the custom factorisation (ragged sizes 1 .. 2112, right-hand-side row, indefinite inputs)
+    with the 64x64-tile update kernel forced onto every launch it can take, and with panel widths that move the panel
+    boundaries -- and with them the shapes the near / far updates and the fused first block see -- to other places."""
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["NMGP_ROUND"] = "variants"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
+                          "-x", "-p", "no:cacheprovider", "-k", "custom_cholesky"], capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, (env_extra, out.stdout[-3000:])
