@@ -293,7 +293,10 @@ def run_chains(a, rank, world, be):
                    "samples_per_s": a.hmc_samples * B * world / h_elapsed, "samples_per_chain": a.hmc_samples,
                    "seconds": h_elapsed, "grad_evals_per_s": evals * world / h_elapsed,
                    "accept_rate_mean": float(np.mean(info["accept_rate"])),
-                   "median_abs_energy_error": float(np.nanmedian(np.abs(info["energy_error"])))}
+                   "median_abs_energy_error": float(np.nanmedian(np.abs(info["energy_error"]))),
+                   "note": "a rate measurement: the chains start from perturbed generating parameters, not from a MAP "
+                           "estimate as Nonseparable_model.py:228 does, so the first trajectories are descents (large "
+                           "negative energy change, always accepted); sampler behaviour is tested in tests/test_drivers.py"}
     # the ONE reduction: every chain of every rank contributes a row
     ids = [rank * B + b for b in range(B)]
     stats, table = chains.reduce_rows(unit_rows(ids, a.steps, out, status), B * world, world, device=be.device)
