@@ -1,6 +1,6 @@
 #!/bin/bash
 # Every profile artefact of a round in ONE call on the GPU box, from the repo root:
-#     bash tools/profile_round.sh <tag>            -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
+#     bash tools/profile_round.sh <tag> [profiles prefix, default r02]   -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
 # kernel-trace + stats runs of the workloads DESIGN section 4b quotes, the default bench line outside the profiler, and the
 # two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace domains) that roofline.traffic is derived from.
 # rocprofv3 is given python3 itself after `--` (nothing that re-execs), TMPDIR on /tmp as the pool's guide prescribes.
@@ -46,5 +46,9 @@ done
 cd "$R"
 python3 tools/pmc_summary.py "$O/batched128_pmc_FETCH_SIZE.csv" "$O/batched128_pmc_WRITE_SIZE.csv" "$O/batched128_pmc_traffic.json" "128 chains, $1"
 python3 tools/pmc_classes.py "$O/batched128_pmc_FETCH_SIZE.csv" "$O/batched128_pmc_WRITE_SIZE.csv" "$O/batched128_pmc_syrk_classes.json"
+# the default line is measured with the fresh traffic pin in place (bench.py reports roofline.traffic only for the kernel source
+# the PMC passes ran on); the pin travels back through gpurun_out/
+mkdir -p profiles && cp "$O/batched128_pmc_traffic.json" "profiles/${2:-r02}_batched128_pmc_traffic.json"
+python3 tools/pin_traffic.py "profiles/${2:-r02}_batched128_pmc_traffic.json" && cp profiles/traffic.json "$O/traffic.json"
 python3 bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
 tail -1 "$O/bench_default.json" | cut -c1-400
