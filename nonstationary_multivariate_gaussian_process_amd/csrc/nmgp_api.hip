@@ -452,7 +452,8 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
     if (want_grad) {
         const size_t NJ = (N + 63) / 64;
-        const size_t need = NJ * (size_t)N * (T + 1);
+        // adjoint partial rows; before that pass the same buffer holds the block sums of alpha = L^-T z (tri_gemv_upper)
+        const size_t need = std::max(NJ * (size_t)N * (T + 1), (size_t)n * ((n + 255) / 256));
         if (!c->d_part || c->part_cap < need) {
             NMGP_TRY(nmgp_dev_alloc(c, &c->d_part, need));
             c->part_cap = need;
@@ -488,10 +489,8 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
             StageScope sp(c, NMGP_STAGE_SOLVE);
             get_row(s, c->d_S, ld, n, c->d_z, n, 1, 0, 0);
             if (want_grad) {
-                // alpha = Sigma^-1 y = L^-T z = X z
-                const double one = 1.0, zero = 0.0;
-                BLAS_TRY(c, rocblas_dgemv(c->blas, rocblas_operation_none, n, n, &one, c->d_S + xoff, ld, c->d_z, 1,
-                                          &zero, c->d_alpha, 1));
+                // alpha = Sigma^-1 y = L^-T z = X z (d_part is free until the adjoint pass: scratch for the block sums)
+                tri_gemv_upper(s, c->d_S + xoff, (int)ld, n, c->d_z, c->d_alpha, c->d_part);
             }
         }
     } else {
@@ -773,7 +772,8 @@ static int batch_grad_alloc(nmgp_ctx* c) {
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_S2, B * ld2 * n));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_Sinv, B * n * n));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_alpha, B * n));
-    NMGP_TRY(nmgp_dev_alloc(c, &c->b_part, B * NJ * N * (T + 1)));
+    // adjoint partial rows (NJ N (T + 1) per chain); before that pass the block sums of alpha = L^-T z (n ceil(n / 256) per chain)
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_part, B * std::max(NJ * N * (T + 1), (size_t)n * ((n + 255) / 256))));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_grad, B * P));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_R2, N * B * (1 + T)));
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_tr, B * 2));
@@ -831,9 +831,9 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         StageScope sp(c, NMGP_STAGE_SOLVE);
         get_row(s, S, ld, n, c->b_z, n, B, bs, n);
         if (want_grad) {
-            const double one = 1.0, zero = 0.0;               // alpha_b = X_b z_b
-            BLAS_TRY(c, rocblas_dgemv_strided_batched(c->blas, rocblas_operation_none, n, n, &one, S + xoff, ld, bs,
-                                                      c->b_z, 1, n, &zero, c->b_alpha, 1, n, B));
+            // alpha_b = X_b z_b (b_part is free until the adjoint pass: scratch for the block sums)
+            tri_gemv_upper(s, S + xoff, (int)ld, n, c->b_z, c->b_alpha, c->b_part, (int)B, bs,
+                           (long long)n * ((n + 255) / 256));
         }
     }
     {

@@ -260,6 +260,10 @@ void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
                 int xstride = 0);
+// out = W z, W upper triangular (n x n, column-major with leading dimension ld; the zeros left of the diagonal are stored);
+// part: n * ceil(n / 256) doubles of scratch per matrix
+void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double* z, double* out, double* part, int batch = 1,
+                    long long wstride = 0, long long pstride = 0);
 void trace_terms(hipStream_t s, const double* alpha, const double* Sinv, int ld, int n, double* out,
                  double ssign = 1.0, int batch = 1);
 void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, const double* Lv, const double* R2,

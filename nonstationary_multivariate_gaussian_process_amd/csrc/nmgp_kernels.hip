@@ -356,6 +356,64 @@ void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, doubl
     NMGP_LAUNCH(k_col_sumsq, dim3(cols), dim3(256), 0, s, R, ld, rows, out);
 }
 
+// alpha = W z for the UPPER-triangular W = L^-T that rides below the factor in a gradient evaluation (W[i, k] at W[i + k ld],
+// exact zeros for k < i): Sigma^-1 y = L^-T (L^-1 y).  The library's dgemv streams all n^2 entries (n = 6144: 322 us, 0.94 TB/s
+// on one matrix); here only the 256 x 256 blocks on and above the diagonal are read, one block per workgroup with lanes along
+// i (512-byte segments per column), and the block sums are added in a fixed order by a second small kernel -- no atomics.
+__global__ __launch_bounds__(256) void k_tri_gemv_part(const double* __restrict__ W, int ld, int n, const double* __restrict__ z,
+                                                        double* __restrict__ part, long long wstride, long long pstride) {
+    const int rb = blockIdx.x, ch = blockIdx.y;
+    if (ch < rb) return;                                  // a block of structural zeros
+    W += (size_t)blockIdx.z * wstride;
+    z += (size_t)blockIdx.z * n;
+    part += (size_t)blockIdx.z * pstride;
+    __shared__ double sz[256];
+    const int tid = threadIdx.x;
+    const int k0 = ch * 256;
+    sz[tid] = (k0 + tid < n) ? z[k0 + tid] : 0.0;
+    __syncthreads();
+    const int i = rb * 256 + tid;
+    if (i >= n) return;
+    const int kn = (n - k0 < 256) ? (n - k0) : 256;
+    const double* col = W + i + (size_t)k0 * ld;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = 0;
+    for (; k + 8 <= kn; k += 8) {                         // eight loads in flight per lane
+        const double w0 = col[(size_t)(k + 0) * ld], w1 = col[(size_t)(k + 1) * ld], w2 = col[(size_t)(k + 2) * ld],
+                     w3 = col[(size_t)(k + 3) * ld], w4 = col[(size_t)(k + 4) * ld], w5 = col[(size_t)(k + 5) * ld],
+                     w6 = col[(size_t)(k + 6) * ld], w7 = col[(size_t)(k + 7) * ld];
+        a0 = fma(w0, sz[k + 0], a0);
+        a1 = fma(w1, sz[k + 1], a1);
+        a2 = fma(w2, sz[k + 2], a2);
+        a3 = fma(w3, sz[k + 3], a3);
+        a0 = fma(w4, sz[k + 4], a0);
+        a1 = fma(w5, sz[k + 5], a1);
+        a2 = fma(w6, sz[k + 6], a2);
+        a3 = fma(w7, sz[k + 7], a3);
+    }
+    for (; k < kn; ++k) a0 = fma(col[(size_t)k * ld], sz[k], a0);
+    part[(size_t)ch * n + i] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void k_tri_gemv_reduce(const double* __restrict__ part, int n, double* __restrict__ out,
+                                                          long long pstride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    part += (size_t)blockIdx.y * pstride;
+    const int nch = (n + 255) / 256;
+    double a = 0.0;
+    for (int ch = i / 256; ch < nch; ++ch) a += part[(size_t)ch * n + i];
+    out[(size_t)blockIdx.y * n + i] = a;
+}
+
+// part: at least n * ceil(n / 256) doubles per matrix, `pstride` apart
+void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double* z, double* out, double* part, int batch,
+                    long long wstride, long long pstride) {
+    const int nb = cdiv(n, 256);
+    NMGP_LAUNCH(k_tri_gemv_part, dim3(nb, nb, batch), dim3(256), 0, s, W, ld, n, z, part, wstride, pstride);
+    NMGP_LAUNCH(k_tri_gemv_reduce, dim3(nb, batch), dim3(256), 0, s, part, n, out, pstride);
+}
+
 // mirror the lower triangle into the upper one (column-major n x n)
 __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld, int n) {
     __shared__ double tile[64][65];
