@@ -659,3 +659,46 @@ def test_separable_and_stationary_objectives_recover_from_a_singular_covariance(
     ctx.set_data(g["x"], g["Y"])
     o2, _ = ctx.logpos_sep(g["pars"], g["hyper"], True, False)
     assert relerr(o2[0], g["out"][0]) < VAL_TOL
+
+
+def test_repeated_evaluations_are_bit_identical_on_the_multi_stream_schedules(ctx):
+    """The latency-regime schedules run three streams at once (panel steps, far trailing updates on the CU-masked stream, prior
+    solves) and hand blocks from one launch to the next through events; every reduction has a fixed order.  A missing
+    dependency would show as run-to-run differences long before it shows as a parity failure: the same inputs, evaluated five
+    times each (value + gradient), must give the same bits -- one chain at N = 2048 (12 panels: look-ahead, small-tile near
+    update with the fused first block), 8 subjects x N = 1024 in one batch, separable N = 4096 x D = 5."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    hv = [sim.HYPER_SVC[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")]
+    d = sim.simulate_nonseparable(2048, 3, seed=2222)
+    pars = sim.perturb(d["pars_true"], 0.05, 0.3)
+    ctx.set_data(d["x"], d["Y"])
+    runs = [ctx.logpos_svc(pars, hv, prior=True, want_grad=True) for _ in range(5)]
+    for out, grad in runs[1:]:
+        assert np.array_equal(out, runs[0][0]) and np.array_equal(grad, runs[0][1])
+    vals = [ctx.logpos_svc(pars, hv, prior=True, want_grad=False)[0] for _ in range(5)]
+    assert all(np.array_equal(v, vals[0]) for v in vals[1:])
+    # 8 subjects in one batch
+    subs = [sim.simulate_nonseparable(1024, 3, seed=s) for s in range(8)]
+    ctx.set_data(subs[0]["x"], subs[0]["Y"])
+    ctx.svc_batch_alloc(8)
+    ctx.svc_batch_set_subjects(np.stack([s["x"] for s in subs]), np.stack([s["Y"] for s in subs]))
+    ctx.svc_batch_set_pars(np.stack([sim.perturb(s["pars_true"], 0.05, 0.3) for s in subs]))
+    hm = [sim.HYPER_SVC_MPISIM[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")]
+    res = []
+    for _ in range(5):
+        ctx.svc_batch_eval(hm, True, want_grad=True)
+        o, st = ctx.svc_batch_fetch()
+        res.append((o.copy(), ctx.svc_batch_fetch_grad().copy()))
+        assert not st.any()
+    for o, g in res[1:]:
+        assert np.array_equal(o, res[0][0]) and np.array_equal(g, res[0][1])
+    ctx.svc_batch_alloc(1)
+    # separable, config 5's shape
+    ds = sim.simulate_separable(4096, 5, 8)
+    ps = sim.perturb(ds["pars_true"], 0.05, 0.4)
+    hs = [sim.HYPER_SEP[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma",
+                                     "beta_tilde_sigma", "a", "b", "c")]
+    ctx.set_data(ds["x"], ds["Y"])
+    sr = [ctx.logpos_sep(ps, hs, True, True) for _ in range(5)]
+    for o, g in sr[1:]:
+        assert np.array_equal(o, sr[0][0]) and np.array_equal(g, sr[0][1])
