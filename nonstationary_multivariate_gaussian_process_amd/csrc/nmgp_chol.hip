@@ -608,128 +608,24 @@ __global__ __launch_bounds__(256) void k_potf2_64(double* __restrict__ A, int ld
 
 // ---------------------------------------------------------------------------------------------
 // 64x64 diagonal block, blocked: four 16-column blocks.  The 64 sequential pivots of k_potf2_64 cost ~960 cycles each
-// (a workgroup barrier, ~10 LDS reads and ~16 masked FMAs per thread and pivot); here only the 16x16 DIAGONAL blocks
-// are factored pivot by pivot -- by ONE wave (no s_barrier; a wave's LDS operations execute in order), 4 columns per
-// lane -- and everything below / right of them goes through the matrix cores:
-//   (A) wave 0: unscaled right-looking factorisation of S_qq; the same row operations applied to the identity give the
-//       unit-lower inverse E (S = L~ D L~^T, E = L~^-1), so inv(L_qq) = D^-1/2 E comes along off the critical path;
-//   (B) X_i = S_iq inv(L_qq)^T for the row blocks below (wave w takes block q + 1 + w; 4 MFMAs each);
-//   (C) S_ij -= X_i X_j^T for q < j <= i (at most 6 tiles of 4 MFMAs over the 4 waves).
-// The block lives in LDS column-major (S[col][row]); every MFMA operand is a plain 8-byte read of it.
+// (a workgroup barrier, ~10 LDS reads and ~16 masked FMAs per thread and pivot); here the 16x16 DIAGONAL blocks are factored
+// by ONE wave in registers (potf2m_group below) and everything below / right of them goes through the matrix cores:
+//   (A) the diagonal block S_qq and, along with it, inv(L_qq);
+//   (B) X_i = S_iq inv(L_qq)^T for the row blocks below (4 MFMAs each);
+//   (C) S_ij -= X_i X_j^T for q < j <= i.
+// The block lives in LDS column-major (S[col][row]); potf2b_core_mfma has the schedule.
 // ---------------------------------------------------------------------------------------------
 #define PB_LD 66
-template <int KC, int GC>
-__device__ __forceinline__ void potf2b_step(double (&a)[4], double (&e)[4], double (*colbuf)[16], double (*rowbuf)[16],
-                                            double* pivs, double* Sqq, int q, int* __restrict__ info, int goff, int r, int g,
-                                            int lane) {
-    constexpr int c = 4 * KC + GC;
-    constexpr int NKC = (GC == 3) ? KC + 1 : KC;          // register slot / owner class of column c + 1
-    constexpr int NGC = (GC == 3) ? 0 : GC + 1;
-    const double* cb = colbuf[c & 1];
-    const double* rb = rowbuf[c & 1];
-    const double piv = cb[c];
-    const double mine = cb[r];
-    double t[4], er[4];
-#pragma unroll
-    for (int kk = KC; kk < 4; ++kk) t[kk] = cb[4 * kk + g];
-#pragma unroll
-    for (int kk = 0; kk <= KC; ++kk) er[kk] = rb[4 * kk + g];
-    const double pinv = fast_recip(piv);
-    const double f = (r > c) ? mine * pinv : 0.0;          // rows up to the pivot row are final
-    // S[r][cc] -= f S[cc][c].  No column masks: column c is final and leaves for LDS right below, so the slots of
-    // columns <= c are dead values from here on and may be clobbered.
-#pragma unroll
-    for (int kk = KC; kk < 4; ++kk) a[kk] = fma(-f, t[kk], a[kk]);
-    // E[r][cc] -= f E[c][cc]: row c of E is zero right of column c, so no mask here either
-#pragma unroll
-    for (int kk = 0; kk <= KC; ++kk) e[kk] = fma(-f, er[kk], e[kk]);
-    if (c + 1 < 16) {
-        if (g == NGC) colbuf[(c + 1) & 1][r] = a[NKC < 4 ? NKC : 3];
-        if (r == c + 1) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) rowbuf[(c + 1) & 1][4 * kk + g] = e[kk];
-        }
-    }
-    // off the critical path: the finished (unscaled) column c goes back to the block, the pivot to pivs
-    if (g == GC) Sqq[c * PB_LD + r] = mine;
-    if (lane == 0) {
-        pivs[16 * q + c] = piv;
-        if (!(piv > 0.0)) atomicCAS(info, 0, goff + 16 * q + c + 1);
-    }
-    __builtin_amdgcn_wave_barrier();                        // keep the LDS writes ahead of the next step's reads
-}
-
-template <int KC>
-__device__ __forceinline__ void potf2b_steps4(double (&a)[4], double (&e)[4], double (*colbuf)[16], double (*rowbuf)[16],
-                                              double* pivs, double* Sqq, int q, int* __restrict__ info, int goff, int r,
-                                              int g, int lane) {
-    potf2b_step<KC, 0>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2b_step<KC, 1>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2b_step<KC, 2>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2b_step<KC, 3>(a, e, colbuf, rowbuf, pivs, Sqq, q, info, goff, r, g, lane);
-}
-
-// The same pivot step with the cross-lane traffic on the DPP / LDS-crossbar paths instead of an LDS write + read round
-// trip: thread (r, g) = (lane >> 2, lane & 3), so that a row's four column classes sit in one quad.  Column c lives in
-// register slot KC of the lanes with g = GC: the pivot comes by v_readlane (compile-time lane), the row's own entry by a
-// DPP quad broadcast, the entries S[4 kk + g][c] and the row E[c][.] by ds_bpermute (no LDS memory involved).
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, srclane);
     hi = __builtin_amdgcn_readlane(hi, srclane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double bperm_f64(double v, int srclane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_bpermute(srclane * 4, lo);
-    hi = __builtin_amdgcn_ds_bpermute(srclane * 4, hi);
-    return __hiloint2double(hi, lo);
-}
-template <int SRC>
-__device__ __forceinline__ double quad_bcast_f64(double v) {
-    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
-template <int KC, int GC>
-__device__ __forceinline__ void potf2x_step(double (&a)[4], double (&e)[4], double* pivs, double* Sqq, int q,
-                                            int* __restrict__ info, int goff, int r, int g, int lane) {
-    constexpr int c = 4 * KC + GC;
-    const double piv = readlane_f64(a[KC], 4 * c + GC);
-    const double mine = quad_bcast_f64<GC>(a[KC]);
-    double t[4], er[4];
-#pragma unroll
-    for (int kk = KC; kk < 4; ++kk) t[kk] = bperm_f64(a[KC], 16 * kk + 4 * g + GC);     // S[4 kk + g][c]
-#pragma unroll
-    for (int kk = 0; kk <= KC; ++kk) er[kk] = bperm_f64(e[kk], 4 * c + g);              // E[c][4 kk + g]
-    const double pinv = fast_recip(piv);
-    const double f = (r > c) ? mine * pinv : 0.0;          // rows up to the pivot row are final
-#pragma unroll
-    for (int kk = KC; kk < 4; ++kk) a[kk] = fma(-f, t[kk], a[kk]);
-#pragma unroll
-    for (int kk = 0; kk <= KC; ++kk) e[kk] = fma(-f, er[kk], e[kk]);
-    if (g == GC) Sqq[c * PB_LD + r] = mine;                // the finished (unscaled) column goes back to the block
-    if (lane == 0) {
-        pivs[16 * q + c] = piv;
-        if (!(piv > 0.0)) atomicCAS(info, 0, goff + 16 * q + c + 1);
-    }
-}
-
-template <int KC>
-__device__ __forceinline__ void potf2x_steps4(double (&a)[4], double (&e)[4], double* pivs, double* Sqq, int q,
-                                              int* __restrict__ info, int goff, int r, int g, int lane) {
-    potf2x_step<KC, 0>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2x_step<KC, 1>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2x_step<KC, 2>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-    potf2x_step<KC, 3>(a, e, pivs, Sqq, q, info, goff, r, g, lane);
-}
 
 // ---- 16x16 diagonal block in 4-column groups on the matrix cores (the default of phase (A) below) -------------------
-// The pivot-by-pivot variants above spend ~460 cycles per pivot, most of it waiting for cross-lane traffic (five exposed
-// ds_bpermute / v_readlane round trips per pivot).  Here the block lives in ONE wave's registers in the MFMA accumulator
+// Pivot by pivot (round 1) a 16x16 block cost ~460 cycles per pivot, most of it waiting for cross-lane traffic (five exposed
+// ds_bpermute / v_readlane round trips).  Here the block lives in ONE wave's registers in the MFMA accumulator
 // layout -- S[i][j] in register i >> 2 of lane j + 16 (i & 3), kept SYMMETRIC, so that the four rows 4 g .. 4 g + 3 are
 // register g and are, as they stand, the B operand (and by symmetry the A operand) of a K = 4 MFMA -- and is factored four
 // columns at a time:
@@ -816,9 +712,6 @@ __device__ __forceinline__ void potf2m_group(v4d& S, v4d& E, double& yfin, doubl
 struct Potf2Lds {
     double S[64 * PB_LD];            // S[col * PB_LD + row]
     double Einv[4][16][17];          // inv(L_qq)[row][col] of the four diagonal blocks
-    double colbuf[2][16];
-    double rowbuf[2][16];
-    double pivs[64];
 };
 
 // Factor the 64x64 block held in P.S (lower triangle valid, strict upper zero).  Called by EVERY thread of the workgroup
