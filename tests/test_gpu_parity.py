@@ -702,3 +702,33 @@ def test_repeated_evaluations_are_bit_identical_on_the_multi_stream_schedules(ct
     sr = [ctx.logpos_sep(ps, hs, True, True) for _ in range(5)]
     for o, g in sr[1:]:
         assert np.array_equal(o, sr[0][0]) and np.array_equal(g, sr[0][1])
+
+
+def test_twice_the_headline_size_against_the_oracle(ctx):
+    """N = 4096, D = 3 (MN = 12288, 24 panels): twice BASELINE's largest single-subject matrix.  The k-loop of the inverse SYRK is
+    then longer than the 32-bit panel offsets of the mask-free tile path allow (it falls back to the generic path), the look-ahead
+    schedule runs 24 panels, the triangular alpha product 48 x 48 blocks: value, components and full gradient against the CPU
+    oracle, plus a central-difference check of the gradient along a smooth direction."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from oracle import nmgp_oracle as O
+    N, M = 4096, 3
+    d = sim.simulate_nonseparable(N, M, 11)
+    pars = sim.perturb(d["pars_true"], 0.05, 0.2)
+    hv = [sim.HYPER_SVC[k] for k in SVC_KEYS]
+    ctx.set_data(d["x"], d["Y"])
+    out, grad = ctx.logpos_svc(pars, hv, prior=True, want_grad=True)
+    val, _ = ctx.logpos_svc(pars, hv, prior=True, want_grad=False)
+    ref, gref = O.nlogpos_obj_SVC(pars, d["Y"], d["x"], **sim.HYPER_SVC, verbose=True, grad=True)
+    errs = dict(neglog=(relerr(out[0], ref[0]), VAL_TOL), loglik=(relerr(out[1], ref[1]), LIK_TOL),
+                priors=(prior_term_err(out[2:4], np.array(ref[2:4]), N), VAL_TOL), grad=(vec_relerr(grad, gref), GRAD_TOL),
+                value_only_vs_grad_path=(relerr(val[0], out[0]), 1e-9))
+    record_parity("svc_sim_N4096_M3_oracle", **errs)
+    for k, (e, tol) in errs.items():
+        assert e < tol, (k, e, tol, out, ref)
+    k = np.arange(pars.shape[0])
+    v = np.sin(0.002 * k + 0.1) * 1e-2
+    eps = 1e-3
+    fp, _ = ctx.logpos_svc(pars + eps * v, hv, prior=True)
+    fm, _ = ctx.logpos_svc(pars - eps * v, hv, prior=True)
+    fd = (fp[0] - fm[0]) / (2 * eps)
+    assert abs(fd - grad @ v) / abs(fd) < 1e-5
