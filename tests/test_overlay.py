@@ -116,3 +116,48 @@ def test_mirror_alone_names_what_is_missing():
     env.pop("PYTHONPATH", None)
     r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALONE-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_utility_imports_of_every_reference_script_resolve_on_the_overlay():
+    """All 17 scripts of the reference that import from ``Utility`` (the three model families, their MPI / simulation / real-data
+    variants, the post-processing and simulation tools): their ``from Utility import ...`` lines -- read from the checkout at
+    test time -- run on the overlay from the script's own directory, and every imported module is either a mirror module or
+    the user's own file."""
+    import glob
+    scripts = sorted(p for p in glob.glob(os.path.join(REF, "*", "*.py"))
+                     if os.path.dirname(p) != os.path.join(REF, "Utility") and "from Utility import" in open(p).read())
+    assert len(scripts) >= 15
+    code = textwrap.dedent('''
+        import os, sys, types, re
+        sys.dont_write_bytecode = True
+        for name in ("HMC_Sampler", "seaborn", "mpi4py", "pyGPs", "statsmodels", "gpytorch"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.path.append("..")              # what every one of these scripts does before its imports
+        sys.path.insert(0, %r)
+        import nonstationary_multivariate_gaussian_process_amd as nmgp_amd
+        nmgp_amd.install_utility_alias()
+        mirror = os.path.join(%r, "nonstationary_multivariate_gaussian_process_amd", "Utility")
+        refutil = %r
+        seen = set()
+        for script in sys.argv[1:]:
+            os.chdir(os.path.dirname(script))
+            lines = [ln.strip() for ln in open(script).read().split("\\n") if re.match(r"\\s*from Utility import ", ln)]
+            assert lines, script
+            ns = {}
+            for ln in lines:
+                exec(ln, ns)
+            for k, v in ns.items():
+                if isinstance(v, types.ModuleType) and k != "__builtins__":
+                    d = os.path.dirname(os.path.abspath(v.__file__))
+                    assert d in (mirror, refutil), (script, k, d)
+                    seen.add((k, d == mirror))
+        mirrored = {k for k, m in seen if m}
+        assert {"logpos", "kernels", "kronecker_operation", "distributions", "utils", "settings", "prediction"} <= mirrored, mirrored
+        assert {"posterior_analysis", "visualization", "empirical_estimation"} <= {k for k, m in seen if not m}
+        print("IMPORTS-OK", len(sys.argv) - 1)
+    ''') % (ROOT, ROOT, os.path.join(REF, "Utility"))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    env.pop("NMGP_REFERENCE_UTILITY", None)
+    r = subprocess.run([sys.executable, "-c", code] + scripts, cwd=os.path.join(REF, "Nonseparable_Model"), env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "IMPORTS-OK" in r.stdout, r.stdout + r.stderr
