@@ -276,7 +276,7 @@ def run_chains(a, rank, world, be):
                                  "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS},
                     "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in g_stage.items() if v[1] > 0}}
     # end-to-end MCMC rate: BatchedHMC (drivers.py) advances the same B chains in lock-step, 20 leapfrog steps per sample
-    # (Nonseparable_model.py:228-231), every step one batched value+gradient launch sequence + the host-side leapfrog update
+    # (Nonseparable_model.py:228-231), every step one batched value+gradient launch sequence + the leapfrog kernels
     hmc_rec = None
     if a.hmc_samples > 0 and prof is not None and max(1, min(a.groups, B)) == 1 and B > 1:
         from nonstationary_multivariate_gaussian_process_amd import drivers
@@ -288,8 +288,9 @@ def run_chains(a, rank, world, be):
         h_elapsed = max_over_ranks(time.perf_counter() - t0, world, be.device)
         evals = (1 + 20 * a.hmc_samples) * B
         hmc_rec = {"what": "BatchedHMC: %d chains in lock-step, 20 leapfrog steps per sample, step size 1e-4, identity mass "
-                           "matrix; one batched value+gradient evaluation per leapfrog step, parameters up / gradients down "
-                           "over PCIe every step" % B,
+                           "matrix; one batched value+gradient evaluation per leapfrog step; positions, momenta and "
+                           "gradients stay in HBM for the whole trajectory (nmgp_svc_batch_traj), per sample the momenta go "
+                           "up and the end point comes down" % B,
                    "samples_per_s": a.hmc_samples * B * world / h_elapsed, "samples_per_chain": a.hmc_samples,
                    "seconds": h_elapsed, "grad_evals_per_s": evals * world / h_elapsed,
                    "accept_rate_mean": float(np.mean(info["accept_rate"])),

@@ -104,6 +104,19 @@ int nmgp_svc_batch_fetch(nmgp_ctx* ctx, double* out, int* status);
 int nmgp_svc_batch_fetch_grad(nmgp_ctx* ctx, double* grad);
 double* nmgp_svc_batch_grad_dev(nmgp_ctx* ctx);
 
+/* Device-resident leapfrog trajectories of the B chains -- the inner loop of the HMC sampler the reference's scripts hand their
+ * potential to (Nonseparable_model.py:228-231: step_size 1e-4, num_steps_in_leap 20; the sampler itself is an external package).
+ * Positions (the batch's parameter vectors), momenta and gradients stay in HBM between the `nsteps` batched value+gradient
+ * evaluations of a trajectory; the caller draws the momenta and the accept uniforms and keeps the potentials.
+ *   nmgp_svc_batch_traj_begin : after a batched value+gradient evaluation of the start positions (set_pars + batch_eval(.., 1))
+ *   nmgp_svc_batch_traj       : p0 [B,P] in; end point q1, p1 [B,P], potential U1 [B] (NegLog; +inf where failed) and
+ *                               failed [B] (1: the potential was undefined somewhere on the trajectory -> reject) out
+ *   nmgp_svc_batch_traj_commit: accept [B]; rejected chains get their pre-trajectory position and gradient back */
+int nmgp_svc_batch_traj_begin(nmgp_ctx* ctx);
+int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
+                        double* q1, double* p1, double* U1, int* failed);
+int nmgp_svc_batch_traj_commit(nmgp_ctx* ctx, const int* accept);
+
 /* Dense covariance of the nonseparable model as the reference assembles it (logpos.py:339-353:
  * K_x, generate_K_index_SVC, the n-major->m-major permutation, kron(ones, K_x) * K_i, + sigma2 I).
  * out: [MN, MN] full symmetric, output-major.  For tests and for callers that want Sigma itself. */

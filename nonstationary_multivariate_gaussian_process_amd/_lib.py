@@ -47,6 +47,9 @@ SIGNATURES = {
     "nmgp_svc_batch_fetch_grad": (I, [V, P]),
     "nmgp_svc_batch_grad_dev": (V, [V]),
     "nmgp_svc_batch_fetch": (I, [V, P, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_traj_begin": (I, [V]),
+    "nmgp_svc_batch_traj": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_covariance": (I, [V, P, P]),
     "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
     "nmgp_logpos_sta": (I, [V, P, P, I, P, P]),
@@ -241,6 +244,32 @@ class Context:
         status = np.zeros(self.B, dtype=np.int32)
         self.check(self.lib.nmgp_svc_batch_fetch(self.h, ptr(out), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
         return out, status
+
+    # -- device-resident leapfrog trajectories of the batch (HMC) ---------------------------------
+    def svc_batch_traj_begin(self):
+        """After set_pars + batch_eval(want_grad=True) at the start positions: positions and gradients become the state
+        the trajectories start from."""
+        self.check(self.lib.nmgp_svc_batch_traj_begin(self.h))
+
+    def svc_batch_traj(self, hyper, prior, eps, nsteps, p0):
+        """One leapfrog trajectory per chain from the resident state with momenta p0 [B, P]: returns the end point
+        (q1, p1 [B, P]), the potential there U1 [B] (inf for failed chains) and failed [B] (bool)."""
+        hyper, p0 = as_f64(hyper), as_f64(p0)
+        P_ = self.N * (1 + self.T) + 1
+        if p0.shape != (self.B, P_):
+            raise NmgpError("momenta must be [B=%d, P=%d], got %s" % (self.B, P_, p0.shape))
+        q1, p1, U1 = np.empty((self.B, P_)), np.empty((self.B, P_)), np.empty(self.B)
+        failed = np.zeros(self.B, dtype=np.int32)
+        self.check(self.lib.nmgp_svc_batch_traj(self.h, ptr(hyper), int(bool(prior)), float(eps), int(nsteps), ptr(p0),
+                                                ptr(q1), ptr(p1), ptr(U1),
+                                                failed.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return q1, p1, U1, failed.astype(bool)
+
+    def svc_batch_traj_commit(self, accept):
+        acc = np.ascontiguousarray(np.asarray(accept).astype(np.int32))
+        if acc.shape != (self.B,):
+            raise NmgpError("accept must be [B=%d]" % self.B)
+        self.check(self.lib.nmgp_svc_batch_traj_commit(self.h, acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
 
     def svc_covariance(self, pars):
         pars = as_f64(pars).reshape(-1)

@@ -639,8 +639,12 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 // Cholesky are then paid once per batch instead of once per chain, and the MFMA trailing updates fill the chip.
 static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
-                       &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr};
+                       &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
+                       &c->b_mom, &c->b_q0, &c->b_g0};
     c->b_grad_ready = false;
+    c->b_traj_ready = false;
+    if (c->b_hmc) hipFree(c->b_hmc);
+    c->b_hmc = nullptr;
     c->b_multi = false;
     if (c->b_x) hipFree(c->b_x);
     if (c->b_y) hipFree(c->b_y);
@@ -689,6 +693,7 @@ extern "C" int nmgp_svc_batch_set_pars(nmgp_ctx* c, const double* pars) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->b_pars, pars, (size_t)c->batch * c->P_svc * sizeof(double), hipMemcpyHostToDevice,
                               c->stream));
+    c->b_traj_ready = false;
     return 0;
 }
 
@@ -788,6 +793,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->N, M = c->M, T = c->T, n = c->n, B = c->batch;
     const long long P = c->P_svc;
+    c->b_traj_ready = false;             // the resident gradient no longer belongs to a trajectory's start point
     if (want_grad) NMGP_TRY(batch_grad_alloc(c));
     // value-only: rows = n + 1 (y); with gradient: + pad + n identity rows (-> L^-T), in the larger buffer
     const int xpad = (n + 1) & 1, xoff = n + 1 + xpad;
@@ -953,6 +959,82 @@ extern "C" int nmgp_svc_batch_fetch(nmgp_ctx* c, double* out, int* status) {
         if (status) status[z] = st;
     }
     return 0;
+}
+
+// ---- device-resident leapfrog trajectories of the B chains (drivers.py BatchedHMC) -----------------------------------------
+// State between calls: b_pars = positions q, b_grad = dU/dq at q (U = NegLog), validity flags; the host keeps U and draws the
+// momenta / the accept uniforms (so a chain reproduces the single-chain sampler's random stream).
+extern "C" int nmgp_svc_batch_traj_begin(nmgp_ctx* c) {
+    if (!c) return NMGP_E_NULL;
+    if (c->batch <= 0 || c->last_kind != 2 || !c->b_last_grad)
+        return nmgp_fail(c, NMGP_E_STATE, "a batched value+gradient evaluation of the start positions must come first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t B = c->batch, P = (size_t)c->P_svc;
+    if (!c->b_mom) {
+        NMGP_TRY(nmgp_dev_alloc(c, &c->b_mom, B * P));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->b_q0, B * P));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->b_g0, B * P));
+        HIP_TRY(c, hipMalloc((void**)&c->b_hmc, 4 * B * sizeof(int)));
+    }
+    hmc_status(c->stream, c->b_info, c->b_scal, c->b_hmc, nullptr, (int)B);
+    c->b_traj_ready = true;
+    return nmgp_take_launch_error(c);
+}
+
+// One trajectory for every chain: p0 [B, P] (host) are the momenta drawn by the caller; `nsteps` leapfrog steps of size `eps`
+// with identity mass matrix, one batched value+gradient evaluation per step.  Returns the end point q1, p1 [B, P], the
+// potential there U1 [B] and failed [B] = 1 for a chain whose potential was undefined at ANY point of the trajectory (to be
+// rejected).  The device then holds the END state; nmgp_svc_batch_traj_commit puts the rejected chains back.
+extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
+                                   double* q1, double* p1, double* U1, int* failed) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper || !p0 || !q1 || !p1 || !U1 || !failed) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
+    if (!c->b_traj_ready) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_begin must be called on the current state");
+    if (nsteps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "nsteps must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int B = c->batch;
+    const long long P = c->P_svc;
+    const size_t bytes = (size_t)B * P * sizeof(double);
+    hipStream_t s = c->stream;
+    int* bad = c->b_hmc;
+    int* bad0 = c->b_hmc + B;
+    int* fl = c->b_hmc + 2 * B;
+    HIP_TRY(c, hipMemcpyAsync(c->b_mom, p0, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->b_q0, c->b_pars, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->b_g0, c->b_grad, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(bad0, bad, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(fl, 0, (size_t)B * sizeof(int), s));
+    hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, 0.5 * eps, eps, 1, P, B);
+    for (int step = 0; step < nsteps; ++step) {
+        NMGP_TRY(nmgp_svc_batch_eval(c, hyper, prior, 1));
+        hmc_status(s, c->b_info, c->b_scal, bad, fl, B);
+        const bool last = step == nsteps - 1;
+        hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, last ? 0.5 * eps : eps, eps, last ? 0 : 1, P, B);
+    }
+    std::vector<double> h((size_t)B * 16);
+    HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(p1, c->b_mom, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(failed, fl, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    NMGP_TRY(nmgp_take_launch_error(c));
+    for (int z = 0; z < B; ++z) U1[z] = failed[z] ? INFINITY : h[(size_t)z * 16 + 8];
+    c->b_traj_ready = true;
+    return 0;
+}
+
+// accept [B]: 1 keeps a chain's end state, 0 restores the position / gradient it had before the trajectory
+extern "C" int nmgp_svc_batch_traj_commit(nmgp_ctx* c, const int* accept) {
+    if (!c) return NMGP_E_NULL;
+    if (!accept) return nmgp_fail(c, NMGP_E_NULL, "accept must not be NULL");
+    if (!c->b_traj_ready || !c->b_mom) return nmgp_fail(c, NMGP_E_STATE, "no trajectory to commit");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int B = c->batch;
+    int* acc = c->b_hmc + 3 * B;
+    HIP_TRY(c, hipMemcpyAsync(acc, accept, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hmc_restore(c->stream, c->b_pars, c->b_grad, c->b_q0, c->b_g0, c->b_hmc, c->b_hmc + B, acc, c->P_svc, B);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));        // `accept` is the caller's buffer
+    return nmgp_take_launch_error(c);
 }
 
 extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out) {

@@ -123,6 +123,12 @@ struct nmgp_ctx {
     double* b_R2 = nullptr;     // [N, B (1+T)]
     double* b_tr = nullptr;     // [B, 2]
     bool b_last_grad = false;
+    // device-resident HMC trajectories (nmgp_svc_batch_traj_*): momenta, the state before the trajectory, validity flags
+    double* b_mom = nullptr;    // [B, P]
+    double* b_q0 = nullptr;     // [B, P]
+    double* b_g0 = nullptr;     // [B, P]
+    int* b_hmc = nullptr;       // [4, B]: bad (current position), bad0 (before the trajectory), failed, accept
+    bool b_traj_ready = false;  // nmgp_svc_batch_traj_begin ran on the current state
     // multi-subject batch: every batch element has its own (x, Y) and its own prior factors
     bool b_multi = false;
     double* b_x = nullptr;      // [B, N]
@@ -257,6 +263,11 @@ void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
 void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
                    int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
+void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B);
+void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
+                    long long P, int B);
+void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
+                 const int* accept, long long P, int B);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
                 int xstride = 0);

@@ -414,6 +414,69 @@ void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double*
     NMGP_LAUNCH(k_tri_gemv_reduce, dim3(nb, batch), dim3(256), 0, s, part, n, out, pstride);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident leapfrog trajectory of B lock-step HMC chains (drivers.py BatchedHMC; Nonseparable_model.py:228-231 hands the
+// same job to the external HMC_Sampler): positions q = the batch's parameter vectors, momenta p and gradients g stay in HBM
+// between the batched value+gradient evaluations of a trajectory.  The arithmetic is the host sampler's, operation for
+// operation (t = c * g; p = p - t; q = q + eps * p; no contraction), so both give the same bits.
+// ---------------------------------------------------------------------------------------------
+// bad[z] = the evaluation that just ran is undefined for chain z (factorisation status or a non-finite value); failed |= bad
+__global__ void k_hmc_status(const int* __restrict__ info, const double* __restrict__ scal, int* __restrict__ bad,
+                             int* __restrict__ failed, int B) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= B) return;
+    const double v0 = scal[(size_t)z * 16 + 8], v1 = scal[(size_t)z * 16 + 9];
+    const int b = (info[z] != 0 || !isfinite(v0) || !isfinite(v1)) ? 1 : 0;
+    bad[z] = b;
+    if (failed && b) failed[z] = 1;
+}
+
+// p -= c * g for the chains whose gradient is defined (the host sampler zeroes the gradient of the others); then, if drift,
+// q += eps * p
+__global__ __launch_bounds__(256) void k_hmc_kick_drift(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ q,
+                                                         const int* __restrict__ bad, double c, double eps, int drift, long long P) {
+    const int z = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t o = (size_t)z * P + i;
+    double pv = p[o];
+    if (!bad[z]) {
+        const double t = c * g[o];
+        pv = pv - t;
+        p[o] = pv;
+    }
+    if (drift) {
+        const double t2 = eps * pv;
+        q[o] = q[o] + t2;
+    }
+}
+
+// rejected chains (accept[z] == 0) get the position, gradient and validity flag they had before the trajectory back
+__global__ __launch_bounds__(256) void k_hmc_restore(double* __restrict__ q, double* __restrict__ g, const double* __restrict__ q0,
+                                                      const double* __restrict__ g0, int* __restrict__ bad,
+                                                      const int* __restrict__ bad0, const int* __restrict__ accept, long long P) {
+    const int z = blockIdx.y;
+    if (accept[z]) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) bad[z] = bad0[z];
+    if (i >= P) return;
+    const size_t o = (size_t)z * P + i;
+    q[o] = q0[o];
+    g[o] = g0[o];
+}
+
+void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B) {
+    NMGP_LAUNCH(k_hmc_status, dim3(cdiv(B, 64)), dim3(64), 0, s, info, scal, bad, failed, B);
+}
+void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
+                    long long P, int B) {
+    NMGP_LAUNCH(k_hmc_kick_drift, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, p, g, q, bad, c, eps, drift, P);
+}
+void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
+                 const int* accept, long long P, int B) {
+    NMGP_LAUNCH(k_hmc_restore, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, q, g, q0, g0, bad, bad0, accept, P);
+}
+
 // mirror the lower triangle into the upper one (column-major n x n)
 __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld, int n) {
     __shared__ double tile[64][65];

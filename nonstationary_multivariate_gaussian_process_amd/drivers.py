@@ -355,9 +355,11 @@ class BatchedHMC(LockStepHMC):
     Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
     """
 
-    def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None):
+    def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
+                 device_resident=True):
         from . import _lib
         super().__init__(init_positions, step_size, num_steps_in_leap, seed)
+        self.device_resident = bool(device_resident)
         self.ctx = ctx if ctx is not None else _lib.default_context()
         keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
         self.hyper = np.array([float(hyper_pars[k]) for k in keys])
@@ -375,3 +377,33 @@ class BatchedHMC(LockStepHMC):
         U[bad] = np.inf
         g[bad] = 0.0
         return U, g
+
+    def run(self, sample_size):
+        """``device_resident=True`` (default): positions, momenta and gradients stay in HBM for the whole trajectory
+        (``nmgp_svc_batch_traj``: the leapfrog updates are elementwise kernels between the batched evaluations); per sample
+        the host uploads the momenta it drew, reads the end point back and decides acceptance -- the same arithmetic and
+        the same random streams as the host-side lock-step loop (``device_resident=False``), bit for bit."""
+        if not self.device_resident:
+            return super().run(sample_size)
+        B, P = self.B, self.P
+        samples = np.zeros((sample_size, B, P))
+        U, _ = self.potential_and_grad(self.q)           # leaves q and dU/dq resident
+        self.ctx.svc_batch_traj_begin()
+        accepted = np.zeros(B)
+        energy_err = np.zeros((sample_size, B))
+        for it in range(sample_size):
+            p0 = np.stack([r.standard_normal(P) for r in self.rngs])
+            H0 = U + 0.5 * (p0 * p0).sum(1)
+            q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
+            U1 = np.where(failed, np.inf, U1)
+            H1 = U1 + 0.5 * (p1 * p1).sum(1)
+            dH = H1 - H0
+            u = np.array([np.log(r.random()) for r in self.rngs])
+            acc = np.isfinite(dH) & (u < -dH)
+            self.ctx.svc_batch_traj_commit(acc)
+            self.q[acc] = q1[acc]
+            U = np.where(acc, U1, U)
+            accepted += acc
+            energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
+            samples[it] = self.q
+        return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
