@@ -353,6 +353,7 @@ class BatchedHMC(LockStepHMC):
     (``nmgp_svc_batch_eval(want_grad=1)``): the chains are the reference's embarrassingly-parallel unit
     (one process each there, ``Nonseparable_model_mpisim.py:305-306``); here they share the GPU's launch latency.
     Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
+    ``x`` [N], ``Y`` [N, M]: B chains of one subject; ``x`` [B, N], ``Y`` [B, N, M]: one chain per subject.
     """
 
     def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
@@ -363,8 +364,17 @@ class BatchedHMC(LockStepHMC):
         self.ctx = ctx if ctx is not None else _lib.default_context()
         keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
         self.hyper = np.array([float(hyper_pars[k]) for k in keys])
-        self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
-        self.ctx.svc_batch_alloc(self.B)
+        x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+        if x.ndim == 2:
+            # one chain per SUBJECT (BASELINE config 4's unit: x [B, N], Y [B, N, M], every subject with its own prior factors)
+            if x.shape[0] != self.B or Y.shape[0] != self.B:
+                raise ValueError("x [B, N] and Y [B, N, M] must have one subject per chain")
+            self.ctx.set_data(x[0], Y[0])
+            self.ctx.svc_batch_alloc(self.B)
+            self.ctx.svc_batch_set_subjects(x, Y)
+        else:
+            self.ctx.set_data(x, Y)
+            self.ctx.svc_batch_alloc(self.B)
 
     def potential_and_grad(self, q):
         """U [B] and dU/dq [B, P]; a chain whose covariance is not positive definite gets U = inf."""
