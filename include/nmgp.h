@@ -117,6 +117,19 @@ int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double 
                         double* q1, double* p1, double* U1, int* failed);
 int nmgp_svc_batch_traj_commit(nmgp_ctx* ctx, const int* accept);
 
+/* Device-resident Adam over the batch -- the MAP loop of Nonseparable_model.py:147-210 (torch.optim.Adam, default betas / eps)
+ * for B chains or, with nmgp_svc_batch_set_subjects, for all subjects of a rank at once (Nonseparable_model_mpisim.py:330-348):
+ * parameters, gradients and moments stay in HBM; per iteration only the B verbose tuples come back.
+ *   nmgp_svc_batch_adam_begin : start points = the batch's parameter vectors (nmgp_svc_batch_set_pars); moments := 0
+ *   nmgp_svc_batch_adam_step  : one value+gradient evaluation + update; out [B,5] are the tuples at the parameters the iteration
+ *                               started from (NaN row for a subject that is no longer alive); alive [B] turns 0 at a subject's
+ *                               first failed evaluation (its parameters stay frozen; the others go on)
+ *   nmgp_svc_batch_get_pars   : the parameter vectors [B,P] as they stand */
+int nmgp_svc_batch_adam_begin(nmgp_ctx* ctx);
+int nmgp_svc_batch_adam_step(nmgp_ctx* ctx, const double hyper[8], int prior, double lr, double beta1, double beta2, double eps,
+                             double* out, int* alive);
+int nmgp_svc_batch_get_pars(nmgp_ctx* ctx, double* pars);
+
 /* Dense covariance of the nonseparable model as the reference assembles it (logpos.py:339-353:
  * K_x, generate_K_index_SVC, the n-major->m-major permutation, kron(ones, K_x) * K_i, + sigma2 I).
  * out: [MN, MN] full symmetric, output-major.  For tests and for callers that want Sigma itself. */

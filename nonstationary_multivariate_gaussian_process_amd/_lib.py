@@ -50,6 +50,9 @@ SIGNATURES = {
     "nmgp_svc_batch_traj_begin": (I, [V]),
     "nmgp_svc_batch_traj": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_adam_begin": (I, [V]),
+    "nmgp_svc_batch_adam_step": (I, [V, P, I, D, D, D, D, P, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_get_pars": (I, [V, P]),
     "nmgp_svc_covariance": (I, [V, P, P]),
     "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
     "nmgp_logpos_sta": (I, [V, P, P, I, P, P]),
@@ -270,6 +273,26 @@ class Context:
         if acc.shape != (self.B,):
             raise NmgpError("accept must be [B=%d]" % self.B)
         self.check(self.lib.nmgp_svc_batch_traj_commit(self.h, acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+
+    # -- device-resident Adam over the batch (MAP) ------------------------------------------------
+    def svc_batch_adam_begin(self):
+        self.check(self.lib.nmgp_svc_batch_adam_begin(self.h))
+
+    def svc_batch_adam_step(self, hyper, prior, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """One Adam iteration of every batch element on the device: returns the verbose tuples [B, 5] at the parameters the
+        iteration started from and alive [B] (bool)."""
+        hyper = as_f64(hyper)
+        out = np.empty((self.B, 5))
+        alive = np.zeros(self.B, dtype=np.int32)
+        self.check(self.lib.nmgp_svc_batch_adam_step(self.h, ptr(hyper), int(bool(prior)), float(lr), float(beta1),
+                                                     float(beta2), float(eps), ptr(out),
+                                                     alive.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out, alive.astype(bool)
+
+    def svc_batch_get_pars(self):
+        pars = np.empty((self.B, self.N * (1 + self.T) + 1))
+        self.check(self.lib.nmgp_svc_batch_get_pars(self.h, ptr(pars)))
+        return pars
 
     def svc_covariance(self, pars):
         pars = as_f64(pars).reshape(-1)

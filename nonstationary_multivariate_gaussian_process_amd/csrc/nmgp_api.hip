@@ -640,7 +640,10 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
-                       &c->b_mom, &c->b_q0, &c->b_g0};
+                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av};
+    if (c->b_alive) hipFree(c->b_alive);
+    c->b_alive = nullptr;
+    c->b_adam_t = -1;
     c->b_grad_ready = false;
     c->b_traj_ready = false;
     if (c->b_hmc) hipFree(c->b_hmc);
@@ -1035,6 +1038,64 @@ extern "C" int nmgp_svc_batch_traj_commit(nmgp_ctx* c, const int* accept) {
     hmc_restore(c->stream, c->b_pars, c->b_grad, c->b_q0, c->b_g0, c->b_hmc, c->b_hmc + B, acc, c->P_svc, B);
     HIP_TRY(c, hipStreamSynchronize(c->stream));        // `accept` is the caller's buffer
     return nmgp_take_launch_error(c);
+}
+
+// ---- device-resident Adam over the batch (drivers.py BatchedMAP; the MAP loop of Nonseparable_model.py:147-210 and, for all
+// subjects of a rank at once, Nonseparable_model_mpisim.py:330-348) --------------------------------------------------------------
+// begin: the batch's parameter vectors (nmgp_svc_batch_set_pars) are the start points; moments zero, every subject alive.
+extern "C" int nmgp_svc_batch_adam_begin(nmgp_ctx* c) {
+    if (!c) return NMGP_E_NULL;
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t B = c->batch, P = (size_t)c->P_svc;
+    if (!c->b_am) {
+        NMGP_TRY(nmgp_dev_alloc(c, &c->b_am, B * P));
+        NMGP_TRY(nmgp_dev_alloc(c, &c->b_av, B * P));
+        HIP_TRY(c, hipMalloc((void**)&c->b_alive, B * sizeof(int)));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->b_am, 0, B * P * sizeof(double), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b_av, 0, B * P * sizeof(double), c->stream));
+    std::vector<int> ones(B, 1);
+    HIP_TRY(c, hipMemcpyAsync(c->b_alive, ones.data(), B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->b_adam_t = 0;
+    return 0;
+}
+
+// One iteration for every subject: batched value+gradient at the resident parameters, then Adam's update on the device.
+// out [B,5]: the verbose tuples AT the parameters the iteration started from (what the reference logs as target_value_hist);
+// alive [B]: 0 from the first failed evaluation of a subject on (its parameters are frozen there).
+extern "C" int nmgp_svc_batch_adam_step(nmgp_ctx* c, const double hyper[8], int prior, double lr, double beta1, double beta2,
+                                        double eps, double* out, int* alive) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper || !out || !alive) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
+    if (c->b_adam_t < 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_adam_begin must be called first");
+    const int B = c->batch;
+    NMGP_TRY(nmgp_svc_batch_eval(c, hyper, prior, 1));
+    const long long t = ++c->b_adam_t;
+    const double bc1 = 1.0 - std::pow(beta1, (double)t);
+    const double bc2s = std::sqrt(1.0 - std::pow(beta2, (double)t));
+    adam_step(c->stream, c->b_pars, c->b_grad, c->b_am, c->b_av, c->b_alive, c->b_info, c->b_scal, beta1, beta2, bc2s, eps,
+              lr / bc1, c->P_svc, B);
+    std::vector<double> h((size_t)B * 16);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(alive, c->b_alive, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    NMGP_TRY(nmgp_take_launch_error(c));
+    for (int z = 0; z < B; ++z)
+        for (int k = 0; k < 5; ++k) out[(size_t)z * 5 + k] = alive[z] ? h[(size_t)z * 16 + 8 + k] : std::nan("");
+    return 0;
+}
+
+// the batch's parameter vectors [B, P] as they stand in HBM
+extern "C" int nmgp_svc_batch_get_pars(nmgp_ctx* c, double* pars) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars) return nmgp_fail(c, NMGP_E_NULL, "pars must not be NULL");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(pars, c->b_pars, (size_t)c->batch * c->P_svc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int nmgp_svc_covariance(nmgp_ctx* c, const double* pars, double* out) {

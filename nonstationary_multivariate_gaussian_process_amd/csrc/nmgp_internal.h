@@ -129,6 +129,11 @@ struct nmgp_ctx {
     double* b_g0 = nullptr;     // [B, P]
     int* b_hmc = nullptr;       // [4, B]: bad (current position), bad0 (before the trajectory), failed, accept
     bool b_traj_ready = false;  // nmgp_svc_batch_traj_begin ran on the current state
+    // device-resident Adam (nmgp_svc_batch_adam_*): moments and the alive flags of the subjects
+    double* b_am = nullptr;     // [B, P]
+    double* b_av = nullptr;     // [B, P]
+    int* b_alive = nullptr;     // [B]
+    long long b_adam_t = -1;    // iterations done; -1 = not started
     // multi-subject batch: every batch element has its own (x, Y) and its own prior factors
     bool b_multi = false;
     double* b_x = nullptr;      // [B, N]
@@ -263,6 +268,8 @@ void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
 void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
                    int batch = 1);
 void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
+void adam_step(hipStream_t s, double* par, const double* g, double* m, double* v, int* alive, const int* info, const double* scal,
+               double b1, double b2, double bc2s, double eps, double step, long long P, int B);
 void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B);
 void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
                     long long P, int B);

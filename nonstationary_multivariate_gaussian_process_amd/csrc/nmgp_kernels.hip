@@ -477,6 +477,47 @@ void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const do
     NMGP_LAUNCH(k_hmc_restore, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, q, g, q0, g0, bad, bad0, accept, P);
 }
 
+// torch.optim.Adam's update (default: no weight decay, no amsgrad) on the batch's parameter vectors, operation for operation as
+// drivers.LockStepMAP spells it on the host: m = m b1 + (1 - b1) g;  v = v b2 + ((1 - b2) g) g;  denom = sqrt(v) / bc2s + eps;
+// P = P - (lr / bc1) (m / denom).  Chains that are no longer alive (a failed evaluation, now or earlier) are left untouched.
+__global__ __launch_bounds__(256) void k_adam_step(double* __restrict__ par, const double* __restrict__ g, double* __restrict__ m,
+                                                    double* __restrict__ v, const int* __restrict__ alive, double b1, double omb1,
+                                                    double b2, double omb2, double bc2s, double eps, double step, long long P) {
+    const int z = blockIdx.y;
+    if (!alive[z]) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t o = (size_t)z * P + i;
+    const double gv = g[o];
+    const double t1 = m[o] * b1, t2 = omb1 * gv;
+    const double mn = t1 + t2;
+    const double t3 = v[o] * b2, t4 = omb2 * gv;
+    const double t5 = t4 * gv;
+    const double vn = t3 + t5;
+    const double t6 = sqrt(vn) / bc2s;
+    const double denom = t6 + eps;
+    const double t7 = mn / denom;
+    const double t8 = step * t7;
+    par[o] = par[o] - t8;
+    m[o] = mn;
+    v[o] = vn;
+}
+
+// alive[z] &= the evaluation that just ran is defined for chain z (see k_hmc_status)
+__global__ void k_alive_update(const int* __restrict__ info, const double* __restrict__ scal, int* __restrict__ alive, int B) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= B) return;
+    const double v0 = scal[(size_t)z * 16 + 8], v1 = scal[(size_t)z * 16 + 9];
+    if (info[z] != 0 || !isfinite(v0) || !isfinite(v1)) alive[z] = 0;
+}
+
+void adam_step(hipStream_t s, double* par, const double* g, double* m, double* v, int* alive, const int* info, const double* scal,
+               double b1, double b2, double bc2s, double eps, double step, long long P, int B) {
+    NMGP_LAUNCH(k_alive_update, dim3(cdiv(B, 64)), dim3(64), 0, s, info, scal, alive, B);
+    NMGP_LAUNCH(k_adam_step, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, par, g, m, v, alive, b1, 1.0 - b1, b2,
+                1.0 - b2, bc2s, eps, step, P);
+}
+
 // mirror the lower triangle into the upper one (column-major n x n)
 __global__ __launch_bounds__(256) void k_sym_fill(double* __restrict__ A, int ld, int n) {
     __shared__ double tile[64][65];

@@ -170,9 +170,10 @@ class BatchedMAP(LockStepMAP):
     iteration is ONE batched value+gradient launch sequence -- BASELINE config 4's per-GPU work (8 subjects x N = 1024) in the
     caller's own loop.  ``xs`` [B, N], ``Ys`` [B, N, M], ``init_pars`` [B, N(1+T)+1]."""
 
-    def __init__(self, xs, Ys, hyper_pars, init_pars, lr=2e-1, ctx=None):
+    def __init__(self, xs, Ys, hyper_pars, init_pars, lr=2e-1, ctx=None, device_resident=True):
         from . import _lib
         super().__init__(init_pars, lr=lr)
+        self.device_resident = bool(device_resident)
         xs = np.ascontiguousarray(xs, dtype=np.float64)
         Ys = np.ascontiguousarray(Ys, dtype=np.float64)
         self.ctx = ctx if ctx is not None else _lib.default_context()
@@ -187,6 +188,30 @@ class BatchedMAP(LockStepMAP):
         self.ctx.svc_batch_eval(self.hyper, True, want_grad=True)
         out, status = self.ctx.svc_batch_fetch()
         return out, self.ctx.svc_batch_fetch_grad(), status
+
+    def step(self):
+        """``device_resident=True`` (default): parameters, gradients and Adam's moments stay in HBM
+        (``nmgp_svc_batch_adam_step``: the update is an elementwise kernel behind the batched evaluation); per iteration only
+        the B verbose tuples come back, ``self.P`` is refreshed at the end of :meth:`run` (or by :meth:`sync_pars`).  Same
+        arithmetic as the host-side update (``device_resident=False``), bit for bit."""
+        if not self.device_resident:
+            return super().step()
+        if self.t == 0:
+            self.ctx.svc_batch_set_pars(self.P)
+            self.ctx.svc_batch_adam_begin()
+        out, alive = self.ctx.svc_batch_adam_step(self.hyper, True, self.lr, self.b1, self.b2, self.eps)
+        self.t += 1
+        self.alive = alive
+        return np.where(alive, out[:, 0], np.inf), out
+
+    def sync_pars(self):
+        if self.device_resident and self.t > 0:
+            self.P = self.ctx.svc_batch_get_pars()
+        return self.P
+
+    def run(self, N_opt, callback=None):
+        _, hist, alive = super().run(N_opt, callback)
+        return self.sync_pars().copy(), hist, alive
 
 
 class HMCSampler:
