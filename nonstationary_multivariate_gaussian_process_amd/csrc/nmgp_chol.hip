@@ -154,9 +154,18 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ A, int lda, int 
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// Defined next to the diagonal-block kernels below.  Tile (0, 0) of an update holds the NEXT diagonal block of the factorisation
+// (the leading 64 x 64 of the updated trapezoid) in the accumulators of two of its waves: instead of storing it, the workgroup
+// moves it to LDS (the operand buffers, free after the k-loop: `lds` = 2 x 4608 contiguous doubles) and factors it on the spot
+// (potf2b_core_mfma) while the launch's other tiles are still being updated -- the block's own launch (one workgroup per matrix,
+// ~20 us with the rest of the chip idle: 48 of them = 6.5 % of a 64-subject evaluation) disappears.
+__device__ __forceinline__ void syrk_fused_first_block(double* lds, const v4d (&acc)[2][2][2], bool owner, int wj,
+                                                       double* __restrict__ C, int ldc, int* __restrict__ info, int goff);
+
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
                                                int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
-                                               int nyr, double* sA0, double* sB0, bool skip00 = false) {
+                                               int nyr, double* sA0, double* sB0, bool skip00 = false,
+                                               int* __restrict__ finfo = nullptr, int fgoff = 0) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -311,7 +320,8 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                     C[(size_t)j * ldc + yrow + l15] = -acc[u][0][t][r];
                 }
     }
-    if (active) {
+    const bool fowner = finfo != nullptr && wi == 0 && wj < 2;      // these two waves hold the 64x64 block to be factored
+    if (active && !fowner) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -328,6 +338,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                 else *reinterpret_cast<double2*>(&C[(size_t)j * ldc + i]) = c;
             }
     }
+    if (finfo != nullptr) syrk_fused_first_block(sA0, acc, fowner, wj, C, ldc, finfo, fgoff);     // workgroup-uniform
 }
 
 // C[i, j] -= sum_k A[i, k] A[j, k]   for 0 <= j < ncols, j <= i < mrows    (A: mrows x K, C: mrows x ncols)
@@ -337,7 +348,8 @@ template <int NWJ, int BK>
 __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int mrows,
                                                int ncols, int K, long long bstride, long long cstride, int ktri, int swz,
                                                int nbatch, int bx, int by, int bz0, double* sAb, double* sBb,
-                                               int tri_row0 = 0x7fffffff, int tri_k0 = 0) {
+                                               int tri_row0 = 0x7fffffff, int tri_k0 = 0, int* __restrict__ finfo = nullptr,
+                                               int fistride = 0, int fgoff = 0) {
     // tri_row0 / tri_k0: rows i >= tri_row0 of A are rows of an upper-triangular matrix riding below the factorisation (L^-T of
     // the gradient evaluation): A[i, k] == 0 for k < (i - tri_row0) - tri_k0, so a tile made of such rows starts its k-loop
     // there instead of multiplying zeros (with 1024-wide panels that was 12 % of the update flop, with 2048-wide ones 25 %)
@@ -369,9 +381,23 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
         const int t = bx, q = t >> 3;
         const int tiles_pm = swz > 0 ? swz : -swz;
         const long long g = swz > 0 ? ((long long)(q >> 6) * 8 + (t & 7)) * 64 + (q & 63) : (long long)t;   // compact tile index
-        bz = (int)(g / tiles_pm);
-        if (bz >= nbatch) return;                                            // padding workgroup
-        int idx = (int)(g - (long long)bz * tiles_pm);
+        int idx;
+        if (finfo != nullptr) {
+            // tile (0, 0) of EVERY matrix first: those workgroups go on to factor a diagonal block and must not start late
+            if (g >= (long long)tiles_pm * nbatch) return;                   // padding workgroup
+            if (g < nbatch) {
+                bz = (int)g;
+                idx = 0;
+            } else {
+                const long long g2 = g - nbatch;
+                bz = (int)(g2 / (tiles_pm - 1));
+                idx = 1 + (int)(g2 - (long long)bz * (tiles_pm - 1));
+            }
+        } else {
+            bz = (int)(g / tiles_pm);
+            if (bz >= nbatch) return;                                        // padding workgroup
+            idx = (int)(g - (long long)bz * tiles_pm);
+        }
         const int gx = (mrows + SY_BM - 1) / SY_BM, gy = (ncols + SY_BM - 1) / SY_BM;
         int c0 = 0, W = 0, cnt = 0;
         for (;; c0 += SY_SB) {                       // strip of W tile columns starting at tile column c0
@@ -422,8 +448,10 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
                 const int z = (row0 - tri_row0 - tri_k0) / BK;        // leading all-zero k-panels of this tile's rows
                 kt0f = z > 0 ? (z & ~1) : 0;                          // (the unrolled loop wants an even number of panels)
             }
+            // finfo: tile (0, 0) goes on to factor its leading 64x64 block (the host sets it only when that tile takes this path)
             syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, kt0f, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
-                           skipq && bi == 0 && bj == 0);
+                           skipq && bi == 0 && bj == 0, (finfo != nullptr && bi == 0 && bj == 0) ? finfo + (size_t)bz * fistride : nullptr,
+                           fgoff);
             return;
         }
     }
@@ -541,11 +569,11 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
 // C[i, j] -= sum_k A[i, k] A[j, k] on the lower trapezoid (see syrk_tile_body): 128x128 tiles, 8 waves of 64x32.
 __global__ __launch_bounds__(512, 4) void k_syrk_lower(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc,
                                                         int mrows, int ncols, int K, long long bstride, long long cstride,
-                                                        int ktri, int swz, int nbatch, int tri_row0, int tri_k0) {
-    __shared__ double sA[2 * SY_BK * SY_LD];
-    __shared__ double sB[2 * SY_BK * SY_LD];
+                                                        int ktri, int swz, int nbatch, int tri_row0, int tri_k0,
+                                                        int* __restrict__ finfo, int fistride, int fgoff) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * SY_BK * SY_LD];      // A panels | B panels (contiguous: see finfo)
     syrk_tile_body<4, SY_BK>(A, lda, C, ldc, mrows, ncols, K, bstride, cstride, ktri, swz, nbatch, blockIdx.x, blockIdx.y,
-                             blockIdx.z, sA, sB, tri_row0, tri_k0);
+                             blockIdx.z, smem, smem + 2 * SY_BK * SY_LD, tri_row0, tri_k0, finfo, fistride, fgoff);
 }
 
 static thread_local const SyrkHook* g_hook = nullptr;   // set by potrf_lower for the duration of one factorisation
@@ -812,6 +840,37 @@ __device__ __forceinline__ void potf2b_store(double* __restrict__ A, int lda, in
     }
 }
 
+__device__ __forceinline__ void syrk_fused_first_block(double* lds, const v4d (&acc)[2][2][2], bool owner, int wj,
+                                                       double* __restrict__ C, int ldc, int* __restrict__ info, int goff) {
+    static_assert(sizeof(Potf2Lds) <= 4 * SY_BK * SY_LD * sizeof(double), "the block's LDS must fit the operand buffers");
+    Potf2Lds& P = *reinterpret_cast<Potf2Lds*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // (the k-loop ended on a barrier; zero fill and block entries go to disjoint addresses)
+    for (int idx = tid; idx < 4096; idx += (int)blockDim.x) {
+        const int r = idx & 63, c = idx >> 6;
+        if (c > r) P.S[c * PB_LD + r] = 0.0;
+    }
+    if (owner) {
+        // accumulators hold MINUS the updated block: i = 32 p + 2 l15 + s, j = 32 wj + 2 (l4 + 4 r) + tj
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 32 * p + 2 * l15 + sx;
+                        const int j = 32 * wj + 2 * (l4 + 4 * r) + tj;
+                        if (i >= j) P.S[j * PB_LD + i] = -acc[p][sx][tj][r];
+                    }
+    }
+    __syncthreads();
+    potf2b_core_mfma(P, info, goff);
+    potf2b_store(C, ldc, 64, P, tid, (int)blockDim.x);
+}
+
 __global__ __launch_bounds__(256) void k_potf2_64b(double* __restrict__ A, int lda, int nb, int* __restrict__ info,
                                                     int goff, long long bstride, int istride) {
     A += (size_t)blockIdx.x * bstride;
@@ -1065,8 +1124,18 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         const double elems = (double)ncols * mrows - 0.5 * (double)ncols * (ncols - 1);
         tok = g_hook->begin(g_hook->user, s, 2.0 * K * elems * batch, 8.0 * batch * (2.0 * elems + (double)mrows * K));
     }
-    NMGP_LAUNCH(k_syrk_lower, pl.grid, dim3(512), 0, s, A, lda, C, ldc, pl.mrows, ncols, K, bstride, cs, pl.kflags,
-                pl.swz, batch, tri_row0, tri_k0);
+    // the NEXT diagonal block inside tile (0, 0): only where that tile takes the mask-free path (the conditions of
+    // syrk_tile_body); the launch then uses the compact 1-D enumeration, whose fused form deals tile (0, 0) of every matrix first
+    const bool fzb = fuse.info != nullptr && !ktri && cs == bstride && pl.mrows >= SY_BM && (ncols >= SY_BM || ncols == 64) &&
+                     (K & 31) == 0 && (long long)(K + 16) * lda * 8 < 0x7fff0000LL;
+    SyrkPlan pf = pl;
+    if (fzb && pf.swz == 0) {
+        pf.grid = dim3((unsigned)((long long)pf.tiles * batch), 1, 1);
+        pf.swz = -pf.tiles;
+    }
+    NMGP_LAUNCH(k_syrk_lower, pf.grid, dim3(512), 0, s, A, lda, C, ldc, pf.mrows, ncols, K, bstride, cs, pf.kflags,
+                pf.swz, batch, tri_row0, tri_k0, fzb ? fuse.info : (int*)nullptr, fuse.istride, fuse.goff);
+    if (fzb) g_first_block_done = 1;
     if (tok && g_hook->end) g_hook->end(g_hook->user, tok);
 }
 
@@ -1734,19 +1803,37 @@ static inline int active_rows(int n, int extra, int xtri, int cend) { return n +
 //  * recursive halving (left half, ONE update of the right half with K = half width, right half): touches the panel's
 //    C entries log2(w/64) times instead of w/128 times and runs only a quarter of the update flop at K = 64 (HBM-bound
 //    at 8 flop/byte), the rest at K = 128 / 256: used for batches, where the launches are throughput-bound.
+static const int g_fuse_potf2 = [] {   // NMGP_CHOL_FUSE_POTF2=0: every diagonal block in a launch of its own (A/B)
+    const char* e = std::getenv("NMGP_CHOL_FUSE_POTF2");
+    return e ? std::atoi(e) : 1;
+}();
+
+// Arm the next syrk_lower call: its tile (0, 0) is the diagonal block at column `goff`, `wnext` columns are left in the panel
+// part that starts there (a full 64-column block is what the fused form factors).
+static void arm_fused_block(int* info, int istride, int goff, int wnext) {
+    if (!g_fuse_potf2 || wnext < 64 || !g_potf2_exports_inv()) return;
+    g_fuse_next.info = info;
+    g_fuse_next.istride = istride;
+    g_fuse_next.goff = goff;
+}
+
 static void factor_panel_rl(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w1, int* info,
                             int batch, long long bs, int is) {
     for (int j0 = c0; j0 < c0 + w1; j0 += 64) {
         const int jb = (c0 + w1 - j0 < 64) ? (c0 + w1 - j0) : 64;
         double* Ajj = A + (size_t)j0 * lda + j0;
-        potf2_64(s, Ajj, lda, jb, info, j0, batch, bs, is);
+        if (!g_first_block_done) potf2_64(s, Ajj, lda, jb, info, j0, batch, bs, is);     // (unless the preceding update factored it)
+        g_first_block_done = 0;
         const int below = active_rows(n, extra, xtri, j0 + jb) - (j0 + jb);
         if (below > 0) {
             double* Apan = A + (size_t)j0 * lda + (j0 + jb);
             trsm_64(s, Ajj, lda, jb, Apan, lda, below, batch, bs);
             const int ncols = c0 + w1 - (j0 + jb);
-            if (ncols > 0)
+            if (ncols > 0) {
+                arm_fused_block(info, is, j0 + jb, ncols);
                 syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1, 0);
+                g_fuse_next.info = nullptr;
+            }
         }
     }
 }
@@ -1755,7 +1842,8 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
                              int batch, long long bs, int is) {
     if (w <= 64) {
         double* Ajj = A + (size_t)c0 * lda + c0;
-        potf2_64(s, Ajj, lda, w, info, c0, batch, bs, is);
+        if (!g_first_block_done) potf2_64(s, Ajj, lda, w, info, c0, batch, bs, is);     // (unless the preceding update factored it)
+        g_first_block_done = 0;
         const int below = active_rows(n, extra, xtri, c0 + w) - (c0 + w);
         if (below > 0) trsm_64(s, Ajj, lda, w, A + (size_t)c0 * lda + (c0 + w), lda, below, batch, bs);
         return;
@@ -1765,9 +1853,12 @@ static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra
     factor_panel_rec(s, A, lda, n, extra, xtri, c0, h, info, batch, bs, is);
     const int c1 = c0 + h;
     const int below = active_rows(n, extra, xtri, c1) - c1;
-    if (below > 0)
+    if (below > 0) {
+        arm_fused_block(info, is, c1, w - h);           // the update's tile (0, 0) holds the diagonal block the right half starts with
         syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0,
                    xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
+        g_fuse_next.info = nullptr;
+    }
     factor_panel_rec(s, A, lda, n, extra, xtri, c1, w - h, info, batch, bs, is);
 }
 
@@ -1805,11 +1896,6 @@ static int g_panel_mode = -1;      // 0 auto, 1 fused, 2 rec, 3 rl
 static int g_fused_max_batch = -1; // NMGP_CHOL_FUSED_MAX_BATCH: largest batch that takes the fused steps under auto; default:
                                    // batch * n <= 73728 (measured: n = 6144: 8 chains 523 vs 503 evals/s, 16 chains 418 vs 616;
                                    // n = 3072: 16 subjects 3211 vs 2729, 24 subjects 3563, 32 subjects 2877 vs 3714)
-
-static const int g_fuse_potf2 = [] {   // NMGP_CHOL_FUSE_POTF2=0: the next panel's first block in a launch of its own (A/B)
-    const char* e = std::getenv("NMGP_CHOL_FUSE_POTF2");
-    return e ? std::atoi(e) : 1;
-}();
 
 static bool panel_takes_fused_steps(int n, int w, int lda, int batch) {
     if (g_panel_mode < 0) {
@@ -1908,10 +1994,13 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
             const int w1 = (n - c0 < nb1) ? (n - c0) : nb1;
             factor_panel(s, A, lda, n, extra, xtri, c0, w1, info, batch, bs, is);
             const int c1 = c0 + w1;
-            if (c1 < n)
+            if (c1 < n) {
+                arm_fused_block(info, is, c1, n - c1 < nb1 ? n - c1 : nb1);
                 syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda,
                            active_rows(n, extra, xtri, c1) - c1, n - c1, w1, batch, bs, -1, 0,
                            xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
+                g_fuse_next.info = nullptr;
+            }
         }
         return;
     }
@@ -1931,11 +2020,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
         // the previous far update also wrote the next panel's columns
         if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
         const int mact = active_rows(n, extra, xtri, c1);
-        if (g_fuse_potf2 && panel_takes_fused_steps(n, w1n, lda, batch)) {
-            g_fuse_next.info = info;
-            g_fuse_next.istride = is;
-            g_fuse_next.goff = c1;
-        }
+        arm_fused_block(info, is, c1, w1n);
         syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, mact - c1, w1n, w1, batch, bs, -1,
                    0, xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
         g_fuse_next.info = nullptr;
