@@ -560,8 +560,8 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
             if (custom) {
                 // -Sigma^-1 = -(L^-T)(L^-T)^T: one more MFMA SYRK over the triangular X (k-panels left of a tile skipped)
                 if (!c->d_Sinv) NMGP_TRY(nmgp_dev_alloc(c, &c->d_Sinv, (size_t)n * n));
-                syrk_lower(s, c->d_S + xoff, ld, c->d_Sinv, n, n, n, n, 1, 0, 0, 1);
-                fill_lower_to_full(s, c->d_Sinv, n, n);
+                // (ktri = 2: both triangles are written, the adjoint pass reads the full symmetric matrix)
+                syrk_lower(s, c->d_S + xoff, ld, c->d_Sinv, n, n, n, n, 1, 0, 0, 2);
                 Sinv = c->d_Sinv;
                 ldi = n;
                 ssign = -1.0;
@@ -907,8 +907,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     if (want_grad) {
         {
             StageScope sp(c, NMGP_STAGE_INVERSE);
-            syrk_lower(s, S + xoff, ld, c->b_Sinv, n, n, n, n, B, bs, (long long)n * n, 1);     // -Sigma^-1 = -X X^T
-            fill_lower_to_full(s, c->b_Sinv, n, n, B);
+            syrk_lower(s, S + xoff, ld, c->b_Sinv, n, n, n, n, B, bs, (long long)n * n, 2);     // -Sigma^-1 = -X X^T, both triangles
         }
         {
             StageScope sp(c, NMGP_STAGE_ADJOINT);

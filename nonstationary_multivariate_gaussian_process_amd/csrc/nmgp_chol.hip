@@ -165,7 +165,7 @@ __device__ __forceinline__ void syrk_fused_first_block(double* lds, const v4d (&
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
                                                int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
                                                int nyr, double* sA0, double* sB0, bool skip00 = false,
-                                               int* __restrict__ finfo = nullptr, int fgoff = 0) {
+                                               int* __restrict__ finfo = nullptr, int fgoff = 0, bool mirror = false) {
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -338,6 +338,31 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
                 else *reinterpret_cast<double2*>(&C[(size_t)j * ldc + i]) = c;
             }
     }
+    if (mirror && active) {
+        // The result is wanted as a FULL symmetric matrix (the inverse covariance of the gradient path): the sub-tile also goes
+        // to its mirror position C[j, i].  Through a wave-private LDS patch (32 x 32, padded), so that the lanes of a store run
+        // along j -- 256 contiguous bytes per column of C -- instead of 8-byte accesses a leading dimension apart.  (The k-loop
+        // ended on a barrier: the operand buffers are free; a wave's LDS operations execute in order.)
+        double* T = sA0 + w * (32 * 33);
+        const int jl = lane & 31, ih = lane >> 5;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(2 * l15 + sx) * 33 + 2 * (l4 + 4 * r) + tj] = -acc[p][sx][tj][r];
+            const int rowm = col0 + wj * 32 + jl;                       // row index of the mirrored element (= j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int il = 2 * q + ih;
+                const int colm = row0 + wi * 64 + 32 * p + il;          // its column index (= i)
+                const double v = T[il * 33 + jl];
+                if (colm > rowm) C[(size_t)colm * ldc + rowm] = v;       // (diagonal tiles: strictly upper only)
+            }
+        }
+    }
     if (finfo != nullptr) syrk_fused_first_block(sA0, acc, fowner, wj, C, ldc, finfo, fgoff);     // workgroup-uniform
 }
 
@@ -357,6 +382,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     // doubles of LDS each
     const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
     const bool skipq = (ktri & 128) != 0;     // the leading 64x64 block of tile (0, 0) belongs to somebody else (k_panel_step)
+    const bool mirror = (ktri & 512) != 0;    // also write the strictly upper triangle (C symmetric): beta = 0 launches only
     const int yrow = nyr ? mrows : -1;
     ktri &= 1;
     constexpr int NT = 128 * NWJ;          // threads
@@ -451,7 +477,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
             // finfo: tile (0, 0) goes on to factor its leading 64x64 block (the host sets it only when that tile takes this path)
             syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, kt0f, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
                            skipq && bi == 0 && bj == 0, (finfo != nullptr && bi == 0 && bj == 0) ? finfo + (size_t)bz * fistride : nullptr,
-                           fgoff);
+                           fgoff, mirror);
             return;
         }
     }
@@ -562,6 +588,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
                     const int i = row0 + wi * 64 + ti * 16 + (lane & 15);
                     const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
                     if (i < mrows && j < ncols && i >= j && !(skip00g && i < 64 && j < 64)) C[(size_t)j * ldc + i] = acc[tj][ti][r];
+                    if (mirror && i < mrows && j < ncols && i > j) C[(size_t)i * ldc + j] = acc[tj][ti][r];   // (edge tiles only)
                 }
     }
 }
@@ -623,7 +650,7 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
             pl.swz = -pl.tiles;
         }
     }
-    pl.kflags = (ktri ? 1 : 0) | yflag;
+    pl.kflags = (ktri ? 1 : 0) | (ktri == 2 ? 512 : 0) | yflag;          // ktri = 2: triangular A, C overwritten, both triangles
     return pl;
 }
 
