@@ -244,6 +244,57 @@ def gen_pred(only):
     save("pred_N64_M3", **out)
 
 
+def gen_pred_grid(only):
+    """Prediction at the size the reference's scripts use it: the 201-point grid linspace(0, 1, 201) of Nonseparable_model.py:333
+    through pointwise_predmap_inhomogeneous (prediction.py:990-1012, one MN x MN eigendecomposition per grid point: minutes
+    here), and the separable / stationary counterparts (pointwise_predmap :410-430, pointwise_predmap_S :1566-1599) on the
+    same grid.  N = 512, D = 3, simulator data (seed 7), parameters = a smooth perturbation of the generating ones."""
+    name = "pred_N512_M3_grid201"
+    if only and not name.startswith(only):
+        return
+    N, M = 512, 3
+    grids = np.linspace(0.0, 1.0, 201)
+    d = sim.simulate_nonseparable(N, M, seed=7)
+    x, Y = d["x"], d["Y"]
+    h = sim.HYPER_SVC
+    p = sim.perturb(d["pars_true"], 0.05, 0.4)
+    tl, uL, tse = logpos.vec2pars_SVC(t(p), N, M)
+    t0 = time.time()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):          # the reference prints every grid point
+        pct, Ls = prediction.pointwise_predmap_inhomogeneous(tl, uL, tse, t(Y), t(x), t(grids), h["mu_tilde_l"],
+                                                             h["alpha_tilde_l"], h["beta_tilde_l"], h["mu_L"], h["alpha_L"],
+                                                             h["beta_L"])
+    out = dict(x=x, Y=Y, grids=grids, svc_pars=p, svc_hyper=hyper_vec(h, SVC_KEYS), svc_pct=pct.numpy(), svc_Lstar=Ls.numpy(),
+               svc_ref_seconds=time.time() - t0)
+    print("  nonseparable grid: %.1f s" % (time.time() - t0), flush=True)
+    ds = sim.simulate_separable(N, M, seed=7)
+    h = sim.HYPER_SEP
+    ps = sim.perturb(ds["pars_true"], 0.05, 0.4)
+    tl, ts, uLv, tse = logpos.vec2pars(t(ps), N, M)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        pct = prediction.pointwise_predmap(tl, ts, uLv, tse, t(ds["Y"]), t(ds["x"]), t(grids), h["mu_tilde_l"],
+                                           h["alpha_tilde_l"], h["beta_tilde_l"], h["mu_tilde_sigma"], h["alpha_tilde_sigma"],
+                                           h["beta_tilde_sigma"])
+    out.update(sep_x=ds["x"], sep_Y=ds["Y"], sep_pars=ps, sep_hyper=hyper_vec(h, SEP_KEYS), sep_pct=pct.numpy(),
+               sep_ref_seconds=time.time() - t0)
+    print("  separable grid: %.1f s" % (time.time() - t0), flush=True)
+    dt = sim.simulate_stationary(N, M, seed=7)
+    pt = dt["pars_true"].copy()
+    pt[:2] += 0.05
+    tl, ts, uLv, tse = logpos.vec2pars_S(t(pt), M)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        pw = prediction.pointwise_predmap_S(tl, ts, uLv, tse, t(dt["Y"]), t(dt["x"]), t(grids))
+        mean, std = prediction.test_predmap_S(tl, ts, uLv, tse, t(dt["Y"]), t(dt["x"]), t(grids))
+    out.update(sta_x=dt["x"], sta_Y=dt["Y"], sta_pars=pt, sta_pct=pw.numpy(), sta_mean=mean.numpy(), sta_std=std.numpy(),
+               sta_ref_seconds=time.time() - t0)
+    print("  stationary grid: %.1f s" % (time.time() - t0), flush=True)
+    save(name, **out)
+
+
 def gen_map(only):
     """MAP trajectory (Nonseparable_model.py:147-183): Adam(lr 0.2) on [tilde_l | uL_vecs | tilde_sigma2_err]."""
     if only and not "map".startswith(only):
@@ -417,6 +468,7 @@ if __name__ == "__main__":
     gen_sep(a.only)
     gen_sta(a.only)
     gen_pred(a.only)
+    gen_pred_grid(a.only)
     gen_map(a.only)
     gen_cfg4(a.only)
     gen_sep_big(a.only)

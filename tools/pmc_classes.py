@@ -1,6 +1,8 @@
 """HBM traffic of k_syrk_lower per launch class (K, ncols) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py.
 
-usage: python tools/pmc_classes.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json [n] [nb1] [batch] [extra]
+usage: python tools/pmc_classes.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json [n] [nb1] [batch] [extra | grad]
+("grad": a value+gradient evaluation -- marker k_svc_grad_final, pad row + n rows of L^-T below the matrix, and the inverse SYRK
+launch, the last k_syrk_lower of the evaluation, reported as its own class)
 
 Replays the batched factorisation's launch schedule (recursive-halving panels + trailing updates, as tools/syrk_classes.py)
 to attach (rows, ncols, K) to the SYRK dispatches of the LAST evaluation in each pass, then reports per class the measured
@@ -15,10 +17,10 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from syrk_classes import schedule  # noqa: E402
 
 
-def last_eval_syrk(path):
+def last_eval_syrk(path, marker="k_svc_finalize"):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    fin = [i for i, r in enumerate(rows) if "k_svc_finalize" in r["Kernel_Name"]]
+    fin = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     ev = rows[fin[-2] + 1: fin[-1] + 1] if len(fin) > 1 else rows
     return [float(r["Counter_Value"]) for r in ev if "k_syrk_lower" in r["Kernel_Name"]]
 
@@ -28,9 +30,14 @@ def main():
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 6144
     nb1 = int(sys.argv[5]) if len(sys.argv) > 5 else 2048
     batch = int(sys.argv[6]) if len(sys.argv) > 6 else 128
-    extra = int(sys.argv[7]) if len(sys.argv) > 7 else 1
-    sched = schedule(n, nb1, extra)
-    f, w = last_eval_syrk(fetch), last_eval_syrk(write)
+    grad = len(sys.argv) > 7 and sys.argv[7] == "grad"
+    extra = 2 if grad else (int(sys.argv[7]) if len(sys.argv) > 7 else 1)
+    sched = schedule(n, nb1, extra, n if grad else 0)
+    marker = "k_svc_grad_final" if grad else "k_svc_finalize"
+    f, w = last_eval_syrk(fetch, marker), last_eval_syrk(write, marker)
+    inv = None
+    if grad:
+        inv = (f.pop(), w.pop())
     if len(f) != len(sched) or len(w) != len(sched):
         raise SystemExit("launch count mismatch: fetch %d, write %d, schedule %d" % (len(f), len(w), len(sched)))
     cls = OrderedDict()
@@ -41,6 +48,10 @@ def main():
         c["measured_bytes"] += 1024.0 * (2.0 * fk + wk)
         c["algorithmic_bytes"] += 8.0 * batch * (2.0 * elems + m * K)
         c["flop"] += 2.0 * K * elems * batch
+    if inv is not None:
+        # -Sigma^-1 = -X X^T: reads the upper-triangular X once (8 n^2 / 2), writes both triangles of the result (8 n^2)
+        cls["inverse (K=n)"] = {"launches": 1, "measured_bytes": 1024.0 * (2.0 * inv[0] + inv[1]),
+                                "algorithmic_bytes": 8.0 * batch * 1.5 * n * n, "flop": batch * float(n) ** 3 / 3.0}
     tot_m = sum(c["measured_bytes"] for c in cls.values())
     tot_a = sum(c["algorithmic_bytes"] for c in cls.values())
     for c in cls.values():

@@ -1,6 +1,8 @@
 """Per-launch-class efficiency of k_syrk_lower from a rocprofv3 kernel trace of `bench.py` (N=2048, D=3 by default).
 
-usage: python tools/syrk_classes.py <kernel_trace.csv> [n] [nb1] [batch]
+usage: python tools/syrk_classes.py <kernel_trace.csv> [n] [nb1] [batch] [grad: 0 | 1]
+grad = 1: a value+gradient evaluation (marker k_svc_grad_final; the factorisation carries the pad row and the n rows of L^-T,
+whose structural zeros are NOT subtracted from the flop figures below; the inverse SYRK launch is listed separately).
 Replays the factorisation's launch schedule (recursive-halving panels + trailing updates) to attach (mrows, ncols, K)
 to the SYRK launches of the LAST evaluation in the trace, then prints time, TFLOP/s and algorithmic TB/s per class.
 """
@@ -9,8 +11,13 @@ import sys
 from collections import defaultdict
 
 
-def schedule(n, nb1, extra=1):
+def schedule(n, nb1, extra=1, xtri=0):
+    """(rows, ncols, K) of every update launch of one factorisation.  xtri > 0: the gradient evaluation, whose `xtri` rows of
+    L^-T ride below the matrix -- the first c1 of them take part once the factorisation has reached column c1."""
     sched = []
+
+    def act(c1):
+        return n + extra + min(c1, xtri) - c1
 
     def rec(c0, w):
         if w <= 64:
@@ -20,7 +27,7 @@ def schedule(n, nb1, extra=1):
             h = ((w - 1) // 64) * 64
         rec(c0, h)
         c1 = c0 + h
-        below = n + extra - c1
+        below = act(c1)
         if below > 0:
             sched.append((below, w - h, h))
         rec(c1, w - h)
@@ -30,7 +37,7 @@ def schedule(n, nb1, extra=1):
         rec(c0, w1)
         c1 = c0 + w1
         if c1 < n:
-            sched.append((n + extra - c1, n - c1, w1))
+            sched.append((act(c1), n - c1, w1))
     return sched
 
 
@@ -39,12 +46,20 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
     nb1 = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     batch = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+    grad = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "k_svc_finalize" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if ("k_svc_grad_final" if grad else "k_svc_finalize") in r["Kernel_Name"]]
     ev = rows[idx[-2] + 1: idx[-1] + 1]
-    sched = schedule(n, nb1)
+    sched = schedule(n, nb1, 2 if grad else 1, n if grad else 0)
     sy = [r for r in ev if "k_syrk" in r["Kernel_Name"]]
+    if grad:
+        # the last k_syrk_lower launch of a value+gradient evaluation is -Sigma^-1 = -X X^T (K = n, triangular operand: n^3/3 flop)
+        inv = sy[-1]
+        sy = sy[:-1]
+        d = (int(inv["End_Timestamp"]) - int(inv["Start_Timestamp"])) * 1e-9
+        fl = batch * float(n) ** 3 / 3.0
+        print("inverse SYRK (K = n = %d, triangular operand)  time=%8.3f ms  %6.1f TF/s on n^3/3 flop per matrix" % (n, d * 1e3, fl / d / 1e12))
     if len(sy) != len(sched):
         raise SystemExit("launch count mismatch: trace %d, schedule %d" % (len(sy), len(sched)))
     agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
