@@ -156,3 +156,34 @@ def test_prediction():
     assert np.allclose(mean, g["sta_mean"], rtol=1e-5, atol=1e-7)
     assert np.allclose(var, g["sta_std"] ** 2, rtol=1e-5, atol=1e-9)
     assert np.allclose(mean, g["sta_pct"][:, 1], rtol=1e-5, atol=1e-7)
+
+
+def test_prediction_on_the_reference_grid():
+    """The 201-point grid of Nonseparable_model.py:333 at N = 512, D = 3 (pointwise_predmap_inhomogeneous, pointwise_predmap,
+    pointwise_predmap_S of the reference): the oracle within the north star's 1e-5 on predictive mean / variance."""
+    g = golden("pred_N512_M3_grid201")
+    N, M = g["Y"].shape
+    xs = g["grids"]
+    assert xs.shape == (201,)
+    h = hyper_dict(g["svc_hyper"], SVC_KEYS)
+    tl, uL, tse = O.vec2pars_SVC(g["svc_pars"], N, M)
+    pct, Ls, mean, var = O.predmap_inhomogeneous(tl, uL, tse, g["Y"], g["x"], xs, h["mu_tilde_l"], h["alpha_tilde_l"],
+                                                 h["beta_tilde_l"], h["mu_L"], h["alpha_L"], h["beta_L"])
+    ref = g["svc_pct"]
+    assert np.allclose(mean, ref[:, 1], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, ((ref[:, 2] - ref[:, 1]) / 1.96) ** 2, rtol=1e-5, atol=1e-9)
+    # L* is a GP regression through RBF(alpha=10, beta=1) + 1e-6 I at N = 512 (condition number ~1e11): the reference solves it
+    # by LU (torch.solve), we by Cholesky -- both backward stable, 2e-7 apart in absolute terms on entries of order one
+    assert np.allclose(Ls, g["svc_Lstar"], rtol=1e-6, atol=1e-6)
+    h = hyper_dict(g["sep_hyper"], SEP_KEYS)
+    tl, ts, uLv, tse = O.vec2pars(g["sep_pars"], N, M)
+    pct, mean, var = O.predmap_separable(tl, ts, uLv, tse, g["sep_Y"], g["sep_x"], xs, h["mu_tilde_l"], h["alpha_tilde_l"],
+                                         h["beta_tilde_l"], h["mu_tilde_sigma"], h["alpha_tilde_sigma"],
+                                         h["beta_tilde_sigma"])
+    ref = g["sep_pct"]
+    assert np.allclose(mean, ref[:, 1], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, ((ref[:, 2] - ref[:, 1]) / 1.96) ** 2, rtol=1e-5, atol=1e-9)
+    tl, ts, uLv, tse = O.vec2pars_S(g["sta_pars"], M)
+    mean, var = O.predmap_stationary(tl, ts, uLv, tse, g["sta_Y"], g["sta_x"], xs)
+    assert np.allclose(mean, g["sta_mean"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(var, g["sta_std"] ** 2, rtol=1e-5, atol=1e-9)
