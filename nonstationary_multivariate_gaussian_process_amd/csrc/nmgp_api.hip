@@ -216,7 +216,10 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
     }
     HIP_TRY(c, hipSetDevice(device));
     if (const char* e = std::getenv("NMGP_CHOL_LOOKAHEAD")) c->chol_lookahead = std::atoi(e);   // default 1: see potrf_lower
-    if (const char* e = std::getenv("NMGP_PRIOR_SOLVE")) c->prior_rocblas = std::strcmp(e, "rocblas") == 0;
+    if (const char* e = std::getenv("NMGP_PRIOR_SOLVE")) {
+        c->prior_rocblas = std::strcmp(e, "rocblas") == 0;
+        c->prior_trsv_all = std::strcmp(e, "trsv") == 0;
+    }
     if (const char* e = std::getenv("NMGP_SEP")) c->sep_algo = (std::strcmp(e, "eig") == 0) ? 0 : 1;
     {
         // Two streams for the look-ahead factorisation: the main stream carries the latency-bound panel steps (and
@@ -520,7 +523,10 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         svc_prior_rhs(ps.sp, c->d_pars, N, T, mu_l, mu_L, c->d_R, N);
         // (a single subject's 1 + T columns stay with the library: k_prior_trsv needs tens of workgroups to win, its
         // 7 workgroups took 0.69 ms against 0.26 ms at N = 2048)
-        if (pl == pL) {
+        const bool subst = c->prior_trsv_all && !c->prior_rocblas && N <= 3500;
+        if (subst) {
+            prior_trsv(ps.sp, false, pl->L, pl->ld, 0, pL->L, pL->ld, 0, c->d_R, N, 1 + T, 1);
+        } else if (pl == pL) {
             BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                       rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R, N));
         } else {
@@ -532,7 +538,9 @@ static int svc_enqueue(nmgp_ctx* c, const double hyper[8], int prior, int want_g
         col_sumsq(ps.sp, c->d_R, N, N, 1 + T, sc + SC_PRIORQ);
         if (want_grad && prior) {
             HIP_TRY(c, hipMemcpyAsync(c->d_R2, c->d_R, (size_t)N * (1 + T) * sizeof(double), hipMemcpyDeviceToDevice, ps.sp));
-            if (pl == pL) {
+            if (subst) {
+                prior_trsv(ps.sp, true, pl->L, pl->ld, 0, pL->L, pL->ld, 0, c->d_R2, N, 1 + T, 1);
+            } else if (pl == pL) {
                 BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                           rocblas_diagonal_non_unit, N, 1 + T, &one, pl->L, pl->ld, c->d_R2, N));
             } else {
@@ -860,10 +868,11 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
             if (pass == 1)
                 HIP_TRY(c, hipMemcpyAsync(c->b_R2, c->b_R, (size_t)N * B * (1 + T) * sizeof(double),
                                           hipMemcpyDeviceToDevice, ps.sp));
-            if (multi && N <= 3500 && B * (1 + T) >= 32 && !c->prior_rocblas) {
-                // per-subject factors, a handful of right-hand sides each: one streaming pass per column (k_prior_trsv)
-                prior_trsv(ps.sp, pass == 1, pl->L, pl->ld, (long long)pl->ld * N, pL->L, pL->ld, (long long)pL->ld * N, R, N, 1 + T,
-                           (int)B);
+            if (N <= 3500 && !c->prior_rocblas && (c->prior_trsv_all || (multi && B * (1 + T) >= 32))) {
+                // one streaming pass per right-hand side over its factor (k_prior_trsv; per-subject factors in a multi-subject
+                // batch, the subject's shared factors otherwise: stride 0)
+                prior_trsv(ps.sp, pass == 1, pl->L, pl->ld, multi ? (long long)pl->ld * N : 0, pL->L, pL->ld,
+                           multi ? (long long)pL->ld * N : 0, R, N, 1 + T, (int)B);
             } else if (multi) {
                 // per-subject factors: strided-batched solves (columns of chain b start at b (1+T) N)
                 const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;

@@ -165,7 +165,11 @@ __device__ __forceinline__ void syrk_fused_first_block(double* lds, const v4d (&
 __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int lda, double* __restrict__ C, int ldc, int K,
                                                int row0, int col0, bool diag, int kt0, bool beta0, int ncw, int yrow,
                                                int nyr, double* sA0, double* sB0, bool skip00 = false,
-                                               int* __restrict__ finfo = nullptr, int fgoff = 0, bool mirror = false) {
+                                               int* __restrict__ finfo = nullptr, int fgoff = 0, bool mirror = false,
+                                               int fresh0 = 0x7fffffff) {
+    // fresh0: rows i >= fresh0 (relative to C) are rows of L^-T that take part in an update for the first time (gradient
+    // evaluation; see potrf_lower): their C entries have never been written -- the accumulators start from zero instead of a
+    // load -- and their A entries left of the diagonal (k < i - fresh0) are structural zeros that nobody wrote either.
     constexpr int BK = 16;
     constexpr int SBUF = BK * SY_LD;             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -223,19 +227,25 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     // acc[p][s][tj][r]: i = row0 + wi*64 + 32p + 2*l15 + s ; j = col0 + wj*32 + 2*(l4 + 4r) + tj
     v4d acc[2][2][2];
     if (active) {
+        // a wave whose 64 rows are all fresh loads nothing (uniform); in the one wave per tile column that straddles the boundary
+        // the fresh lanes sit the loads out (fresh0 is even: a row pair never straddles)
+        const int rw0 = __builtin_amdgcn_readfirstlane(row0 + wi * 64);
+        const bool wload = !beta0 && rw0 < fresh0;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < 2; ++p) {
+            const int i = row0 + wi * 64 + 32 * p + 2 * l15;
+            const bool old = i < fresh0;
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = row0 + wi * 64 + 32 * p + 2 * l15;
                     const int j = col0 + wj * 32 + 2 * (l4 + 4 * r) + tj;
                     double2 c = make_double2(0.0, 0.0);
-                    if (!beta0) c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);     // uniform branch
+                    if (wload && old) c = *reinterpret_cast<const double2*>(&C[(size_t)j * ldc + i]);
                     acc[p][0][tj][r] = -c.x;
                     acc[p][1][tj][r] = -c.y;
                 }
+        }
     }
     // accumulators of a y-wave live in acc[u][0][t]: columns j = col0 + 64 (wj - 2) + 32 u + 2 (l4 + 4 r) + t, extra row l15
     if (ywave) {
@@ -246,7 +256,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = col0 + 64 * (wj - 2) + 32 * u + 2 * (l4 + 4 * r) + t;
-                    acc[u][0][t][r] = (l15 < nyr) ? -C[(size_t)j * ldc + yrow + l15] : 0.0;
+                    acc[u][0][t][r] = (l15 < nyr && yrow + l15 < fresh0) ? -C[(size_t)j * ldc + yrow + l15] : 0.0;
                 }
     }
     sstore(0);
@@ -282,7 +292,9 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
         }
     };
     const double* rY = sA0 + 64 * (wj - 2) + 2 * l15 + l4 * SY_LD;      // j-side rows of a y-wave (only used by y-waves)
-    auto compute_y = [&](int buf) {
+    // extra row l15 of a gradient evaluation is a fresh row of L^-T: structurally zero -- and never written -- for k < yrow + l15 - fresh0
+    const int yz = (l15 < nyr) ? yrow + l15 - fresh0 - l4 : 0x7fffffff;
+    auto compute_y = [&](int buf, int kb) {
         const double* tB = rY + buf * SBUF;
         const double* ty = sY + buf * 256 + l15 * 16 + l4;
 #pragma unroll
@@ -290,7 +302,7 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
             const v2d f0 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD);
             const v2d f1 = *reinterpret_cast<const v2d*>(tB + kk * 4 * SY_LD + 32);
             const double yv = ty[4 * kk];
-            const double fy = (l15 < nyr) ? yv : 0.0;
+            const double fy = (kb + 4 * kk >= yz) ? yv : 0.0;
             acc[0][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[0], fy, acc[0][0][0], 0, 0, 0);
             acc[0][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[1], fy, acc[0][0][1], 0, 0, 0);
             acc[1][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[0], fy, acc[1][0][0], 0, 0, 0);
@@ -300,12 +312,12 @@ __device__ __forceinline__ void syrk_tile_fast(const double* __restrict__ A, int
     for (int kt = kt0; kt < nk; kt += 2) {         // nk - kt0 is even
         gload();
         if (active) compute(0);
-        else if (ywave) compute_y(0);
+        else if (ywave) compute_y(0, kt * BK);
         sstore(1);
         __syncthreads();
         if (kt + 2 < nk) gload();
         if (active) compute(1);
-        else if (ywave) compute_y(1);
+        else if (ywave) compute_y(1, kt * BK + BK);
         if (kt + 2 < nk) sstore(0);
         __syncthreads();
     }
@@ -385,6 +397,8 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     const bool mirror = (ktri & 512) != 0;    // also write the strictly upper triangle (C symmetric): beta = 0 launches only
     const int yrow = nyr ? mrows : -1;
     ktri &= 1;
+    // rows of L^-T that enter the factorisation with this launch (potrf_lower): the caller describes them by (tri_row0, tri_k0)
+    const int fresh0 = tri_row0 == 0x7fffffff ? 0x7fffffff : tri_row0 + tri_k0;
     constexpr int NT = 128 * NWJ;          // threads
     constexpr int CW = 128 / NWJ;          // columns per wave
     constexpr int TJ = CW / 16;            // MFMA tiles per wave along j
@@ -477,7 +491,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
             // finfo: tile (0, 0) goes on to factor its leading 64x64 block (the host sets it only when that tile takes this path)
             syrk_tile_fast(A, lda, C, ldc, K, row0, col0, diag, kt0f, ktri != 0, ncw, yrow, nyr, &sA[0][0], &sB[0][0],
                            skipq && bi == 0 && bj == 0, (finfo != nullptr && bi == 0 && bj == 0) ? finfo + (size_t)bz * fistride : nullptr,
-                           fgoff, mirror);
+                           fgoff, mirror, fresh0);
             return;
         }
     }
@@ -539,6 +553,15 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
                 const int j = col0 + wj * CW + tj * 16 + (lane >> 4) + 4 * r;
                 acc[tj][ti][r] = (!ktri && active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
             }
+    if (row0 + SY_BM > fresh0) {          // (uniform) fresh rows start from zero whatever their memory holds: see syrk_tile_fast
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[tj][ti][r] = (row0 + wi * 64 + ti * 16 + (lane & 15) >= fresh0) ? 0.0 : acc[tj][ti][r];
+    }
     sstore(0, kt0 * BK);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
@@ -1028,6 +1051,7 @@ __global__ __launch_bounds__(256) void k_syrk_small(const double* __restrict__ A
     int kt0 = 0;                                  // leading all-zero k-panels of triangular rows (see syrk_tile_body)
     if (row0 >= tri_row0 && row0 - tri_row0 - tri_k0 > 0) kt0 = (row0 - tri_row0 - tri_k0) / 16;
     if (kt0 > nk - 1) kt0 = nk - 1;
+    const int fresh0 = tri_row0 == 0x7fffffff ? 0x7fffffff : tri_row0 + tri_k0;     // rows whose C nobody has written yet
     gload(ra[0], rb[0], kt0 * 16);
     gload(ra[1], rb[1], (kt0 + 1) * 16);
     // acc[tj][ti][r]: C element (i, j), i = row0 + 32 wi + 16 ti + l15, j = col0 + 32 wj + 16 tj + l4 + 4 r
@@ -1040,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_syrk_small(const double* __restrict__ A
             for (int r = 0; r < 4; ++r) {
                 const int i = row0 + wi * 32 + ti * 16 + l15;
                 const int j = col0 + wj * 32 + tj * 16 + l4 + 4 * r;
-                acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j) ? C[(size_t)j * ldc + i] : 0.0;
+                acc[tj][ti][r] = (active && i < mrows && j < ncols && i >= j && i < fresh0) ? C[(size_t)j * ldc + i] : 0.0;
             }
     sstore(ra[0], rb[0], 0, kt0 * 16);
     gload(ra[0], rb[0], (kt0 + 2) * 16);
@@ -1524,8 +1548,11 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
-                                                        int u_tiles, int nbatch, int pre,
+                                                        int u_tiles, int nbatch, int pre, int un_fresh, int u_tri,
                                                         long long* __restrict__ stamps) {
+    // un_fresh / u_tri (gradient evaluations; 0x7fffffff otherwise): rows >= un_fresh (absolute) are rows of L^-T whose
+    // entries in column block k + 1 nobody has written yet (they start from zero); u_tri = the same boundary for the update
+    // role, relative to its C origin (see potrf_lower on "fresh" rows)
     // developer aid (NMGP_STEP_STAMPS=<file>): thread 0 of workgroup 0 of matrix 0 records the 100 MHz wall clock at the
     // phase boundaries of the critical workgroup
 #define PS_STAMP(i)                                                              \
@@ -1547,7 +1574,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         const double* Ap = Ab + (size_t)(ck - 64) * lda + (ck + 128);
         double* Cp = Ab + (size_t)(ck + 128) * lda + (ck + 128);
         syrk_tile_body<4, SY_BK>(Ap, lda, Cp, lda, u_mrows, u_ncols, 64, bstride, bstride, u_kflags, -u_tiles, nbatch, t, 0,
-                                 0, smem, smem + 2 * SY_BK * SY_LD);
+                                 0, smem, smem + 2 * SY_BK * SY_LD, u_tri, 0);
         return;
     }
     // ---- solve role ----
@@ -1611,7 +1638,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
             const int c = 16 * q + 4 * r + l4;
             Tk[q][r] = rv ? A[(size_t)(ck + c) * lda + rowc] : 0.0;
             Xp[q][r] = (rv && has_prev) ? Lp[(size_t)c * lda + rowc] : 0.0;
-            Un[q][r] = (rv && has_next) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
+            Un[q][r] = (rv && has_next && row < un_fresh) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
         }
     // (2) operands to LDS
     if (has_prev) {
@@ -1858,7 +1885,8 @@ static void factor_panel_rl(hipStream_t s, double* A, int lda, int n, int extra,
             const int ncols = c0 + w1 - (j0 + jb);
             if (ncols > 0) {
                 arm_fused_block(info, is, j0 + jb, ncols);
-                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1, 0);
+                syrk_lower(s, Apan, lda, A + (size_t)(j0 + jb) * lda + (j0 + jb), lda, below, ncols, jb, batch, bs, -1, 0,
+                           xtri > 0 ? n + extra - (j0 + jb) : 0x7fffffff, j0);
                 g_fuse_next.info = nullptr;
             }
         }
@@ -1913,8 +1941,13 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         const int pre = (ck + 192 <= c0 + w) ? 1 : 0;            // block (k+2, k+2) lies inside the panel: see the P waves
         if (pre) pl.kflags |= 128;                                // ... which own it: the update role skips that block
         long long* st = (g_stamps && ck / 64 < g_stamps_cap) ? g_stamps + (size_t)(ck / 64) * 16 : nullptr;
+        // rows of L^-T that nobody has written yet in the columns this step touches first (see potrf_lower): row r of L^-T
+        // (absolute row n + extra + r) enters with step r / 64 of its panel; its column block k + 1 is first touched by the
+        // solve role of that step and of the next one, everything further right by the update role one step later
+        const int un_fresh = xtri > 0 ? n + extra + (has_prev ? ck - 64 : ck) : 0x7fffffff;
+        const int u_tri = xtri > 0 ? n + extra - 192 : 0x7fffffff;
         NMGP_LAUNCH(k_panel_step, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
-                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, st);
+                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, un_fresh, u_tri, st);
     }
 }
 
@@ -1948,9 +1981,14 @@ static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, in
 
 // Blocked Cholesky of the n x n lower triangle of A.  Below the matrix the same array may hold
 //   * `extra` dense rows R (rows n .. n+extra-1): on exit R L^-T (a right-hand side y becomes z = L^-1 y), and
-//   * `xtri` identity rows (rows n+extra .. n+extra+xtri-1, initialised to I by the caller): on exit L^-T, from which
+//   * `xtri` identity rows (rows n+extra .. n+extra+xtri-1, seeded by identity_rows()): on exit L^-T, from which
 //     Sigma^-1 = (L^-T)(L^-T)^T follows with one more SYRK.  Row r of L^-T is zero left of column r, so only the
 //     first `cend` of these rows take part while the factorisation is at column cend (n^3/3 extra flop, not n^3).
+//     The caller seeds only a band of each row (k_xtri_seed).  Row r ENTERS with the panel [c0, c1) its index lies in: the
+//     launch that applies that panel to the columns right of it is the first to touch X[r, c >= c1], so the update kernels
+//     start the launch's last c1 - c0 rows ("fresh" rows: tri_row0 + tri_k0 onwards) from zero instead of loading them,
+//     and every later launch finds them written.  Every update call of a gradient factorisation therefore passes
+//     (tri_row0, tri_k0).
 // Look-ahead over two streams: after panel k is factored on `s`, only the NEXT panel's columns are updated on `s`
 // (so that panel k+1 can start at once) while the rest of the trailing matrix is updated on `s2`, concurrently with
 // the latency-bound 64-wide steps of panel k+1.  ev[] must hold at least 2 * ceil(n / nb1) + 1 events; s2 == nullptr
@@ -2067,17 +2105,38 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     if (prevB) hipStreamWaitEvent(s, ev[2 + 2 * (k - 1)], 0);
 }
 
-// rows [row0, row0 + pad) := 0 and rows [row0 + pad, row0 + pad + n) := identity (the seed of L^-T) in the n columns
-// of A.  The pad row keeps the identity block at an even row offset (16-byte vector loads of the later SYRK).
-__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ A, int lda, int row0, int n, int pad,
-                                                        long long bstride) {
-    const int r = blockIdx.x * 256 + threadIdx.x;          // 0 .. pad + n - 1
-    const int c = blockIdx.y;
-    if (r < n + pad) A[(size_t)blockIdx.z * bstride + (size_t)c * lda + row0 + r] = (r - pad == c) ? 1.0 : 0.0;
+// Seed of the rows that turn into X = L^-T during a gradient evaluation (rows row0 + pad .. row0 + pad + n - 1 of the
+// factorisation buffer, n columns) -- what used to be a full "identity rows" write of n^2 doubles per matrix (38.7 GB per
+// 128-chain step, 12 ms).  Only what somebody READS BEFORE WRITING is initialised:
+//   * the `pad` rows (dense rows that take part from the first column on): zero;
+//   * row r of X, columns [64 (r/64 - 3), 64 (r/64 + 1)): the identity.  Its diagonal 64 x 64 block is what the panel solve
+//     turns into L^-T; the three blocks left of it are structural zeros that the update kernels read as operands because their
+//     k-loops skip leading zero k-panels per TILE, not per row (reach <= 158 columns left of the diagonal), the inverse SYRK
+//     (k-loop from the tile's first row: reach 127) and the triangular matrix-vector product (256-wide blocks: reach 255).
+// Everything right of the diagonal block is written by the factorisation before it is read: a row enters the factorisation
+// with the panel its index lies in, and the update kernels start such "fresh" rows from zero instead of loading them
+// (syrk_tile_fast & co.: fresh0; k_panel_step: un_fresh, u_tri).  Everything further left is never touched.
+__global__ __launch_bounds__(256) void k_xtri_seed(double* __restrict__ A, int lda, int row0, int n, int pad,
+                                                    long long bstride) {
+    A += (size_t)blockIdx.z * bstride;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (blockIdx.x == gridDim.x - 1) {                      // the pad rows
+        for (int c = blockIdx.y * 256 + threadIdx.x; c < n; c += 256 * gridDim.y)
+            for (int q = 0; q < pad; ++q) A[(size_t)c * lda + row0 + q] = 0.0;
+        return;
+    }
+    const int b = blockIdx.x;                                // 64-row block of X; blockIdx.y = which of the four 64-column blocks
+    const int r = 64 * b + lane;
+    const int cb = b - 3 + (int)blockIdx.y;
+    if (cb < 0 || r >= n) return;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int c = 64 * cb + w + 4 * k;
+        if (c < n) A[(size_t)c * lda + row0 + pad + r] = (r == c) ? 1.0 : 0.0;
+    }
 }
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch, long long bstride) {
-    NMGP_LAUNCH(k_identity_rows, dim3(cdiv_c(n + pad, 256), n, batch), dim3(256), 0, s, A, lda, row0, n, pad,
-                       bstride);
+    NMGP_LAUNCH(k_xtri_seed, dim3(cdiv_c(n, 64) + 1, 4, batch), dim3(256), 0, s, A, lda, row0, n, pad, bstride);
 }
 
 }  // namespace nmgpk

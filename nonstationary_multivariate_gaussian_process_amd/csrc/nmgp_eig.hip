@@ -262,12 +262,17 @@ void dB_to_guL(const std::vector<double>& dB, const std::vector<double>& L, int 
 int prior_solve(nmgp_ctx* c, rocblas_handle hb, hipStream_t sp, PriorFactor* pf, double* R, int ncol, double* R2) {
     const double one = 1.0;
     const int N = c->N;
-    BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
+    const bool subst = c->prior_trsv_all && !c->prior_rocblas && N <= 3500;       // by substitution: see gp_project
+    if (subst) prior_trsv(sp, false, pf->L, pf->ld, 0, pf->L, pf->ld, 0, R, N, ncol, 1);
+    else
+        BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                  rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
     if (R2) {
         HIP_TRY(c, hipMemcpyAsync(R2, R, (size_t)N * ncol * sizeof(double), hipMemcpyDeviceToDevice, sp));
-        BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                  rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R2, N));
+        if (subst) prior_trsv(sp, true, pf->L, pf->ld, 0, pf->L, pf->ld, 0, R2, N, ncol, 1);
+        else
+            BLAS_TRY(c, rocblas_dtrsm(hb, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                      rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R2, N));
     }
     return 0;
 }
@@ -327,15 +332,16 @@ int kron_chol_loglik(nmgp_ctx* c, EigWork& w, double sigma2, bool want_grad, dou
     if (!want_grad) return 0;
     double* Cneg;
     NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, (size_t)M * N * N, &Cneg));
+    double* part;
+    const size_t tri_part = (size_t)N * ((N + 255) / 256);           // block sums of the triangular matrix-vector product, per block
+    NMGP_TRY(nmgp_scratch_get(c, SL_PART, std::max((size_t)M * tri_part, (size_t)((N + 63) / 64) * N * 2 + (size_t)M * 128 * 3 + 8), &part));
     {
         NmgpStage sp(c, NMGP_STAGE_INVERSE);
-        const double one = 1.0, zero = 0.0;
-        BLAS_TRY(c, rocblas_dgemv_strided_batched(c->blas, rocblas_operation_none, N, N, &one, S + xoff, ld, bs, z, 1, N,
-                                                  &zero, alpha, 1, N, M));                       // alpha_p = X_p z_p
+        // alpha_p = X_p z_p over the blocks on and above the diagonal only: X = L^-T is upper triangular, and what lies below
+        // its diagonal band was never written (k_xtri_seed)
+        tri_gemv_upper(s, S + xoff, ld, N, z, alpha, part, M, bs, (long long)tri_part);
         syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, M, bs, (long long)N * N, 1);              // -S_p^-1
     }
-    double* part;
-    NMGP_TRY(nmgp_scratch_get(c, SL_PART, (size_t)M * 128 * 3 + 8, &part));
     const int G = sep_traces(s, Cneg, c->d_K, alpha, N, M, part);
     std::vector<double> hp((size_t)M * G * 3);
     HIP_TRY(c, hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -807,22 +813,33 @@ extern "C" int nmgp_kron_inv_logdet(nmgp_ctx* c, double sigma2, const double* B,
 // =================================================================================================
 // deterministic prediction
 // =================================================================================================
-// GP-regression of the latent curves at new inputs (prediction.py:926-941): proj[s, k] = k*(xs_s)^T Sigma^-1 r_k
-// with r_k the k-th column of R (already value - mean).  Kstar is built as RBF(xs, x) row-major [S, N] ==
-// column-major [N, S].  proj: column-major [S, ncol].
-static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, double* R /*[N,ncol] -> solved*/,
-                      int ncol, double* proj) {
+// GP-regression of the latent curves at new inputs (prediction.py:926-941): proj[s, k] = (Sigma^-1 k*(xs_s))^T r_k with r_k
+// the k-th column of R (already value - mean).  Kstar is built as RBF(xs, x) row-major [S, N] == column-major [N, S].
+// proj: column-major [S, ncol].
+// The ORDER is the reference's (proj_l = solve(Sigma_l, k_l), then the dot product with the curve): Sigma = RBF + 1e-6 I has a
+// condition number of ~1e11, k* lies in its smooth eigenspace and Sigma^-1 k* is a vector of moderate size, whereas
+// Sigma^-1 r amplifies whatever roughness the curve r has by 1e6 and leaves the result to cancellation in k*^T (Sigma^-1 r):
+// solving for r first put L* 3.5e-6 away from the reference at N = 512 (this order: the level of the CPU oracle).
+static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, const double* R /*[N,ncol]*/, int ncol,
+                      double* proj) {
     const int N = c->N;
     hipStream_t s = c->stream;
     const double one = 1.0, zero = 0.0;
     double* Ks;
     NMGP_TRY(nmgp_scratch_get(c, SL_X, (size_t)N * S, &Ks));
     rbf_cov_rect(s, d_xs, S, c->d_x, N, 1, pf->alpha, pf->beta, false, Ks);
-    // w = Sigma^-1 r through the cached Cholesky factor
-    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
-    BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                              rocblas_diagonal_non_unit, N, ncol, &one, pf->L, pf->ld, R, N));
+    // W = Sigma^-1 K* through the cached Cholesky factor (S right-hand sides).  By substitution (k_prior_trsv: true divisions,
+    // one workgroup per right-hand side): the library's trsm multiplies by INVERTED 128 x 128 diagonal blocks, which costs
+    // digits on a factor of condition number ~1e5.5 (NMGP_PRIOR_SOLVE=rocblas selects it; sizes beyond the kernel's LDS too)
+    if (N <= 3500 && !c->prior_rocblas) {
+        prior_trsv(s, false, pf->L, pf->ld, 0, pf->L, pf->ld, 0, Ks, N, S, 1);
+        prior_trsv(s, true, pf->L, pf->ld, 0, pf->L, pf->ld, 0, Ks, N, S, 1);
+    } else {
+        BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                  rocblas_diagonal_non_unit, N, S, &one, pf->L, pf->ld, Ks, N));
+        BLAS_TRY(c, rocblas_dtrsm(c->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                  rocblas_diagonal_non_unit, N, S, &one, pf->L, pf->ld, Ks, N));
+    }
     BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, S, ncol, N, &one, Ks, N, R,
                               N, &zero, proj, S));
     return 0;
@@ -847,7 +864,7 @@ extern "C" int nmgp_predict_svc(nmgp_ctx* c, const double* pars, const double hy
     NMGP_TRY(nmgp_get_prior(c, al_L, be_L, &pL));
     NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
     double* sm;
-    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)S * (2 + 2 * T + 3 * M) + 16, &sm));
+    NMGP_TRY(nmgp_scratch_get(c, SL_Y, (size_t)S * (3 + 2 * T + 3 * M) + 16, &sm));      // xs | proj | tl* | L* | mean | colsq | var
     double* d_xs = sm;
     double* proj = d_xs + S;                      // [S, 1+T]
     double* tl_star = proj + (size_t)S * (1 + T);

@@ -143,7 +143,13 @@ struct nmgp_ctx {
     int last_kind = 0;          // 1 svc
 
     int chol_algo = 1;          // 0 = rocSOLVER dpotrf + rocBLAS dtrsv, 1 = custom blocked factorisation (nmgp_chol.hip)
-    bool prior_rocblas = false;               // NMGP_PRIOR_SOLVE=rocblas: library batched trsm for per-subject prior factors
+    bool prior_rocblas = false;               // NMGP_PRIOR_SOLVE=rocblas: library trsm for every GP-prior solve
+    bool prior_trsv_all = false;              // NMGP_PRIOR_SOLVE=trsv: every GP-prior solve of the objectives by substitution
+                                              // (k_prior_trsv), also one subject's right-hand sides, which default to the library
+                                              // (measured: identical parity figures -- the prior terms' distance to the reference is
+                                              // the FACTOR's conditioning, not the solve -- and 4 ms slower per 128-chain step).
+                                              // Prediction always solves by substitution: there the library's inverted diagonal
+                                              // blocks cost two digits (gp_project)
     int chol_nb1 = 0;           // outer panel width of the custom factorisation; 0 = auto (1024 for batches of large matrices, else 512)
     int profiling = 0;                        // 0 off, 1 stage timers, 2 + one event pair per k_syrk_lower launch
     StageTimer timers[NMGP_STAGE_COUNT];

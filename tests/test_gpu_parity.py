@@ -359,6 +359,29 @@ def test_prediction_on_the_reference_grid(ctx):
     assert np.allclose(pw.numpy(), g["svc_pct"], rtol=1e-5, atol=1e-7)
 
 
+def test_prediction_many_grid_points_on_a_fresh_context():
+    """A context that has done nothing else predicts on 201 points (the scratch block of nmgp_predict_svc was sized for <= 16 grid
+    points and only survived behind larger earlier allocations); small N, against the oracle."""
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    from oracle import nmgp_oracle as O
+    N, M = 64, 3
+    x, Y = sim.rngfree_inputs(N, M)
+    p = sim.rngfree_pars_svc(N, M)
+    h = sim.HYPER_SVC
+    xs = np.linspace(0.0, 1.0, 201)
+    c = _lib.Context(0)
+    try:
+        c.set_data(x, Y)
+        mean, var, Ls = c.predict_svc(p, [h[k] for k in SVC_KEYS], xs)
+    finally:
+        c.close()
+    tl, uL, tse = O.vec2pars_SVC(p, N, M)
+    _, Lo, mo, vo = O.predmap_inhomogeneous(tl, uL, tse, Y, x, xs, h["mu_tilde_l"], h["alpha_tilde_l"], h["beta_tilde_l"],
+                                            h["mu_L"], h["alpha_L"], h["beta_L"])
+    assert np.allclose(mean, mo, rtol=1e-5, atol=1e-7) and np.allclose(var, vo, rtol=1e-5, atol=1e-9)
+    assert np.allclose(Ls, Lo, rtol=1e-6, atol=1e-6)
+
+
 # ---------------------------------------------------------------------------------------------------
 # custom blocked Cholesky (nmgp_chol.hip): FP64-MFMA SYRK, 64-wide panel steps, right-hand side as an extra row
 # ---------------------------------------------------------------------------------------------------
