@@ -51,7 +51,7 @@ CHOL_SOURCE = os.path.join(ROOT, "nonstationary_multivariate_gaussian_process_am
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def measured_traffic(N, M, chains, want_grad=False):
+def measured_traffic(N, M, chains, want_grad=False, workload="chain"):
     """HBM bytes of the k_syrk_lower launches of one step, as measured by the rocprofv3 PMC passes whose summary is
     committed under profiles/ (FETCH_SIZE x2 for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md).  The figure belongs to the
     kernel source it was measured on: profiles/traffic.json stores the SHA-256 of csrc/nmgp_chol.hip next to it and the
@@ -64,11 +64,12 @@ def measured_traffic(N, M, chains, want_grad=False):
     except Exception as e:      # noqa: BLE001
         return None, "no committed PMC measurement (%s)" % type(e).__name__
     for e in entries:
-        if (e["N"], e["M"], e["chains"], bool(e.get("grad", False))) == (N, M, chains, bool(want_grad)):
+        if (e["N"], e["M"], e["chains"], bool(e.get("grad", False)), e.get("workload", "chain")) == (
+                N, M, chains, bool(want_grad), workload):
             if e["chol_sha256"] != sha:
                 return None, "stale: %s was measured on another revision of csrc/nmgp_chol.hip" % e["source"]
             return float(e["bytes_per_step"]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % e["source"]
-    return None, "no committed PMC measurement for N=%d, M=%d, %d chains" % (N, M, chains)
+    return None, "no committed PMC measurement for N=%d, M=%d, %d %s%s" % (N, M, chains, workload, ", value+gradient" if want_grad else "")
 
 
 # ---- product backend: libnmgp_hip.so on one MI355X per rank, RCCL between ranks -------------------------------------
@@ -80,7 +81,15 @@ class HipBackend:
         import torch
         self.torch = torch
         self.local_rank = local_rank
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev:
+            raise SystemExit("bench.py: LOCAL_RANK=%d but this process sees %d GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
+                             "= %r / %r): one rank per GPU needs --nproc-per-node <= visible GPUs" % (
+                                 local_rank, ndev, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
         torch.cuda.set_device(local_rank)
+
+    def device_count(self):
+        return self.torch.cuda.device_count()
 
     def init_dist(self, rank, world):
         import torch.distributed as dist
@@ -198,6 +207,31 @@ def max_over_ranks(elapsed, world, device):
     return float(t[0])
 
 
+def per_rank(value, world, device):
+    """The same scalar of every rank, in rank order (first-contact diagnostics of a multi-GPU run: which rank is the slow one)."""
+    if world == 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o[0]) for o in out]
+
+
+def dist_report(be, world, rank_seconds, steps):
+    """What the process group looked like from rank 0, and the spread of the ranks' own step times (the headline uses the max)."""
+    rep = {"world_size_env": world, "ms_per_step_by_rank": [1e3 * t / max(steps, 1) for t in rank_seconds],
+           "ms_per_step_min_rank": 1e3 * min(rank_seconds) / max(steps, 1),
+           "ms_per_step_max_rank": 1e3 * max(rank_seconds) / max(steps, 1)}
+    dc = getattr(be, "device_count", None)
+    rep["gpus_visible_to_rank0"] = dc() if dc else None
+    if world > 1:
+        import torch.distributed as dist
+        rep["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
+    return rep
+
+
 def timed_steps(be, ev, world, steps, want_grad):
     """EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides; the max over ranks."""
     out = status = None
@@ -206,7 +240,9 @@ def timed_steps(be, ev, world, steps, want_grad):
     for _ in range(steps):
         out, status = ev.step(want_grad)
     barrier(be, ev, world)
-    return max_over_ranks(time.perf_counter() - t0, world, be.device), out, status
+    mine = time.perf_counter() - t0
+    timed_steps.rank_seconds = per_rank(mine, world, be.device)      # kept for the `distributed` object of the JSON line
+    return max_over_ranks(mine, world, be.device), out, status
 
 
 def unit_rows(ids, steps, outs, status):
@@ -239,6 +275,7 @@ def run_chains(a, rank, world, be):
     if prof is not None:
         prof.profile_reset()
     elapsed, out, status = timed_steps(be, ev, world, a.steps, want_grad)
+    rank_seconds = timed_steps.rank_seconds
     stage = prof.profile_read() if prof is not None else {}
     kprof = None
     if prof is not None:
@@ -325,8 +362,12 @@ def run_chains(a, rank, world, be):
             rec["grad"] = grad_rec
         if hmc_rec is not None:
             rec["hmc"] = hmc_rec
+        rec["distributed"] = dist_report(be, world, rank_seconds, a.steps)
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(d, allp[0], hyper, a.cpu_evals, want_grad)
+            rec["cpu_baseline"] = cpu_baseline(d, allp[0], hyper, a.cpu_evals, want_grad, a.cpu_grad_evals)
+        elif world > 1:
+            rec["cpu_baseline_note"] = ("absent on purpose: the CPU oracle is timed by rank 0 of single-GPU runs only (N=1), so that "
+                                        "the multi-GPU lines measure nothing but the GPUs")
     ev.close()
     return rec, stats, table
 
@@ -352,12 +393,16 @@ def hip_chain_report(a, ctx, stage, kprof, B, n, want_grad):
     cov_bytes = B0 * 8.0 * n * (n + 1) / 2.0
     try:
         dgemm_tf = ctx.measure_dgemm_tflops(4096, 5)
-        hbm_gbs = ctx.measure_hbm_gbs(1 << 30, 10)
+        hbm = ctx.measure_hbm_rates(1 << 30, 10)
     except Exception:       # noqa: BLE001 -- measurement helpers are informative only
-        dgemm_tf, hbm_gbs = None, None
+        dgemm_tf, hbm = None, {"copy": None, "read": None, "write": None}
     traffic, traffic_note = measured_traffic(N, M, B, want_grad)
     return {
-        "config_extra": {"stage_ms": stage_ms, "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm_gbs,
+        "config_extra": {"stage_ms": stage_ms, "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm["copy"],
+                         "measured_hbm_read_gbs": hbm["read"], "measured_hbm_write_gbs": hbm["write"],
+                         "measured_hbm_note": "flat 16-byte-per-lane streaming kernels over 1 GiB buffers (tools/lab/hbm_lab.hip has "
+                                              "the sweep; in-place read-modify-write of column-major panels tops out at ~5.1 TB/s, "
+                                              "8-byte-per-lane panel writes at ~5.5 TB/s on the same chip: profiles/r03_hbm_lab*.txt)",
                          "cov_build_gbs": (cov_bytes / (cov_ms * 1e-3) / 1e9) if cov_ms > 0 else None},
         "roofline": {"kernel": "k_syrk_lower (v_mfma_f64_16x16x4_f64 trailing update of the blocked FP64 Cholesky of "
                                "%d %dx%d covariances): achieved = sum over launches of 2K*(updated lower-trapezoid "
@@ -396,6 +441,7 @@ def run_subjects(a, rank, world, be):
     if prof is not None:
         prof.profile_reset()
     elapsed, outs, status = timed_steps(be, ev, world, a.steps, want_grad)
+    rank_seconds = timed_steps.rank_seconds
     stage = prof.profile_read() if prof is not None else {}
     if prof is not None:
         prof.profile_enable(False)
@@ -407,6 +453,7 @@ def run_subjects(a, rank, world, be):
         chol_s = stage_ms.get("chol", 0.0) * 1e-3
         fact_tf = (len(mine) * (2.0 if want_grad else 1.0) * float(n) ** 3 / 3.0) / chol_s / 1e12 if chol_s > 0 else 0.0
         total = a.steps * n_subj
+        traffic, traffic_note = measured_traffic(N, M, len(mine), want_grad, "subjects")
         rec = {
             "metric": "log-posterior evals/sec (%d subjects, N=%d, D=%d nonseparable GP)" % (n_subj, N, M),
             "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -421,7 +468,11 @@ def run_subjects(a, rank, world, be):
                                    "kernels%s): subjects * n^3/3 flop%s over the HIP-event stage time" % (
                                        ", with the L^-T rows" if want_grad else "", " x 2" if want_grad else ""),
                          "bound": "mfma", "achieved": fact_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fact_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None}}
+                         "frac": fact_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note},
+            "distributed": dist_report(be, world, rank_seconds, a.steps)}
+        if world > 1:
+            rec["cpu_baseline_note"] = ("absent on purpose: the CPU oracle is timed by rank 0 of single-GPU runs only (N=1); the "
+                                        "single-GPU chain workload's line carries it")
     ev.close()
     return rec, stats, table
 
@@ -448,7 +499,9 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=1,
                     help="split the chains into this many groups, each a batched context on its own pair of HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-evals", type=int, default=3)
+    ap.add_argument("--cpu-evals", type=int, default=5, help="timed value evaluations of the CPU oracle (cpu_baseline; median)")
+    ap.add_argument("--cpu-grad-evals", type=int, default=2,
+                    help="timed value+gradient evaluations of the CPU oracle (cpu_baseline.grad, next to the `grad` object)")
     return ap.parse_args(argv)
 
 
@@ -475,7 +528,7 @@ def main(argv=None, backend=None):
     return rec, stats, table
 
 
-def cpu_baseline(d, pars, hyper, evals, want_grad):
+def cpu_baseline(d, pars, hyper, evals, want_grad, grad_evals=0):
     """The CPU oracle on the same subject: 1 warm-up + `evals` timed evaluations in the Cholesky formulation, then ONE
     timed evaluation in the reference's own formulation (dense inverse + logdet, logpos.py:352-353) so that the speed-up
     is not inflated by the reference's wasteful formulation.  `cores` = the BLAS/LAPACK threads NumPy/SciPy
@@ -503,6 +556,24 @@ def cpu_baseline(d, pars, hyper, evals, want_grad):
     one("reference")
     t_ref = time.perf_counter() - t0
     N, M = d["Y"].shape
+    grad_rec = None
+    if grad_evals > 0 and not want_grad:
+        tg = []
+        for _ in range(grad_evals):
+            t0 = time.perf_counter()
+            O.nlogpos_obj_SVC(pars, d["Y"], d["x"], **hyper, verbose=True, formulation="cholesky", grad=True)
+            tg.append(time.perf_counter() - t0)
+        mg = float(np.median(tg))
+        grad_rec = {"value": 1.0 / mg, "unit": "evals/s",
+                    "sample": "%d value+gradient evaluations of the same subject (median %.2f s each), NumPy/SciPy oracle with "
+                              "analytic adjoints, Cholesky formulation: the CPU figure beside the `grad` object" % (grad_evals, mg)}
+    rec = _cpu_rec(med, cores, evals, N, M, want_grad, t_ref)
+    if grad_rec is not None:
+        rec["grad"] = grad_rec
+    return rec
+
+
+def _cpu_rec(med, cores, evals, N, M, want_grad, t_ref):
     return {"value": 1.0 / med, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "%d evaluations of the same N=%d, D=%d subject (median %.2f s each), NumPy/SciPy oracle, "
                       "Cholesky formulation, %s" % (evals, N, M, med, "value+gradient" if want_grad else "value only"),

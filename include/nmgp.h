@@ -224,9 +224,17 @@ int nmgp_profile_reset(nmgp_ctx* ctx);
  * mrows x K panel read once). */
 int nmgp_profile_read_work(nmgp_ctx* ctx, double ms[NMGP_STAGE_COUNT], long long count[NMGP_STAGE_COUNT],
                            double flop[NMGP_STAGE_COUNT], double bytes[NMGP_STAGE_COUNT]);
+/* Jitter retries the last nmgp_logpos_sep / nmgp_logpos_sta evaluation needed: 0 = value and gradient are those of the exact
+ * covariance, k > 0 = of the covariance with k x 1e-6 added to the diagonals of B and K_x (the reference retries a NaN
+ * likelihood with RANDOM jitter of that size, logpos.py:267-268 / distributions.py:55-96; here any numerical failure of the
+ * first attempt -- NaN or a non-positive pivot -- triggers the deterministic retry).  -1 for a NULL context. */
+int nmgp_last_sep_attempts(const nmgp_ctx* ctx);
 /* Micro-benchmarks used to state measured peaks next to the spec ones: HBM stream (GB/s) and a
  * rocBLAS dgemm of size n (TFLOP/s). */
 int nmgp_measure_hbm_gbs(nmgp_ctx* ctx, long long bytes, int reps, double* gbs);
+/* gbs3 = {copy (read + write bytes counted), read only, write only}: the chip's streaming ceilings as measured in the run, the
+ * figures the HBM-bound kernels are judged against (flat 16-byte-per-lane kernels, tools/lab/hbm_lab.hip). */
+int nmgp_measure_hbm_rates(nmgp_ctx* ctx, long long bytes, int reps, double gbs3[3]);
 int nmgp_measure_dgemm_tflops(nmgp_ctx* ctx, int n, int reps, double* tflops);
 
 #ifdef __cplusplus

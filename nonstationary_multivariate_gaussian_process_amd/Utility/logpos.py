@@ -171,9 +171,11 @@ def nlogpos_obj(pars, Y, x, mu_tilde_l=0., alpha_tilde_l=1., beta_tilde_l=1., mu
 def logpos(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde_l, beta_tilde_l, mu_tilde_sigma,
            alpha_tilde_sigma, beta_tilde_sigma, a, b, c, verbose=False, Prior=True):
     """Log joint posterior of the separable model; reference logpos.py:237-296 (Kronecker eigen-trick likelihood
-    of distributions.py:26-52, two GP priors, Normal(0,c) on uL_vec, inverse-gamma, Jacobian).  A numerical failure of
-    the first attempt yields NaN like the reference's; its random-jitter retry loop (:267-268) is nondeterministic
-    and is not reproduced."""
+    of distributions.py:26-52, two GP priors, Normal(0,c) on uL_vec, inverse-gamma, Jacobian).  The reference retries a NaN
+    likelihood with RANDOM diagonal jitter (:267-268, multivariate_normal_logpdf1); the library retries a numerically failed
+    first attempt with DETERMINISTIC jitter (attempt x 1e-6 on both diagonals, up to NMGP_SEP_RETRIES times; value and gradient
+    then belong to that regularised covariance) and reports how many retries the last evaluation needed through
+    ``_lib.Context.last_sep_attempts()``; only if every attempt fails is the result NaN."""
     hyper = [_f(mu_tilde_l), _f(alpha_tilde_l), _f(beta_tilde_l), _f(mu_tilde_sigma), _f(alpha_tilde_sigma),
              _f(beta_tilde_sigma), _f(a), _f(b), _f(c)]
     res = _FusedObjective.apply("sep", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),

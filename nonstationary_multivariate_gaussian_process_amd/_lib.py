@@ -73,7 +73,9 @@ SIGNATURES = {
     "nmgp_profile_read": (I, [V, P, c_ll_p]),
     "nmgp_profile_reset": (I, [V]),
     "nmgp_profile_read_work": (I, [V, P, c_ll_p, P, P]),
+    "nmgp_last_sep_attempts": (I, [V]),
     "nmgp_measure_hbm_gbs": (I, [V, ctypes.c_longlong, I, P]),
+    "nmgp_measure_hbm_rates": (I, [V, ctypes.c_longlong, I, P]),
     "nmgp_measure_dgemm_tflops": (I, [V, I, I, P]),
 }
 
@@ -452,10 +454,20 @@ class Context:
         self.check(self.lib.nmgp_profile_read_work(self.h, ptr(ms), cnt.ctypes.data_as(c_ll_p), ptr(work), ptr(nbytes)))
         return {s: (float(ms[k]), int(cnt[k]), float(work[k]), float(nbytes[k])) for k, s in enumerate(STAGES)}
 
+    def last_sep_attempts(self):
+        """Jitter retries the last separable / stationary evaluation needed (0: the exact covariance was evaluated)."""
+        return int(self.lib.nmgp_last_sep_attempts(self.h))
+
     def measure_hbm_gbs(self, nbytes=1 << 30, reps=10):
         out = np.empty(1)
         self.check(self.lib.nmgp_measure_hbm_gbs(self.h, int(nbytes), int(reps), ptr(out)))
         return float(out[0])
+
+    def measure_hbm_rates(self, nbytes=1 << 30, reps=10):
+        """{copy, read, write} GB/s of the library's flat streaming kernels (the HBM ceilings as measured in this run)."""
+        out = np.empty(3)
+        self.check(self.lib.nmgp_measure_hbm_rates(self.h, int(nbytes), int(reps), ptr(out)))
+        return {"copy": float(out[0]), "read": float(out[1]), "write": float(out[2])}
 
     def measure_dgemm_tflops(self, n=4096, reps=5):
         out = np.empty(1)

@@ -92,6 +92,7 @@ def map_subjects(subjects, xs, Ys, init_pars, hyper_pars, world_size, rank, N_op
             rows[k, 0] = subjects[idx]
             rows[k, 1] = 1.0 if alive[k] else 0.0
             rows[k, 2] = N_opt
-            rows[k, 3:8] = last["out"][k] if alive[k] else [math.inf, 0.0, 0.0, 0.0, 0.0]
+            # (N_opt = 0: no iteration ran, there is no objective value to report -- inf, like a subject that failed)
+            rows[k, 3:8] = last["out"][k] if (alive[k] and "out" in last) else [math.inf, 0.0, 0.0, 0.0, 0.0]
     stats, table = reduce_rows(rows, len(subjects), world_size, device=device)
     return pars_local, rows, stats, table

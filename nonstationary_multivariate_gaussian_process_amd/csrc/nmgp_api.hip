@@ -236,10 +236,14 @@ extern "C" int nmgp_ctx_create(int device, nmgp_ctx** out) {
         else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         int la_cus = 64;
         if (const char* e = std::getenv("NMGP_LOOKAHEAD_CUS")) la_cus = std::atoi(e);
-        hipDeviceProp_t prop;
+        hipDeviceProp_t prop{};
         int ncu = 0;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (la_cus > 0 && la_cus < ncu) {
+        // The mask's layout (bit i = CU i / 8 of XCD i % 8) is MI355X's: 8 XCDs x 32 CUs.  On any other device the look-ahead stream
+        // is a plain low-priority stream.  (hipExtStreamCreateWithCUMask makes a BLOCKING stream -- it synchronises with the legacy
+        // NULL stream, which the library never uses -- and carries no priority; both are irrelevant next to the mask.)
+        const bool mi355 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 && ncu == 256;
+        if (mi355 && la_cus > 0 && la_cus < ncu) {
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
             for (int i = la_cus; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
             if (hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
@@ -894,13 +898,15 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
                 BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
                                           B * (1 + T), &one, pl->L, pl->ld, R, N));
             } else {
-                for (int z = 0; z < B; ++z) {
-                    double* Rz = R + (size_t)z * (1 + T) * N;
-                    BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
-                                              rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, Rz, N));
-                    BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
-                                              rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, Rz + N, N));
-                }
+                // two factors shared by all chains (alpha_l / beta_l differ from alpha_L / beta_L, e.g. the reference's
+                // _distributed hyper-parameters): column 0 of every chain against the first, its T other columns against the
+                // second -- two strided-batched calls with factor stride 0 instead of 2 B library calls
+                const rocblas_stride sB = (rocblas_stride)(1 + T) * N;
+                BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
+                                                          rocblas_diagonal_non_unit, N, 1, &one, pl->L, pl->ld, 0, R, N, sB, B));
+                BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
+                                                          rocblas_diagonal_non_unit, N, T, &one, pL->L, pL->ld, 0, R + N, N, sB,
+                                                          B));
             }
             if (pass == 0) col_sumsq(ps.sp, c->b_R, N, N, B * (1 + T), c->b_q);
         }
@@ -1017,7 +1023,18 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
     HIP_TRY(c, hipMemsetAsync(fl, 0, (size_t)B * sizeof(int), s));
     hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, 0.5 * eps, eps, 1, P, B);
     for (int step = 0; step < nsteps; ++step) {
-        NMGP_TRY(nmgp_svc_batch_eval(c, hyper, prior, 1));
+        if (int rc = nmgp_svc_batch_eval(c, hyper, prior, 1)) {
+            // an API-level failure in the middle of a trajectory (not a chain's numerical failure: those are flags): put the
+            // start state back and demand a fresh value+gradient evaluation before the next nmgp_svc_batch_traj_begin, so
+            // that a caller who retries cannot continue from a half-advanced position
+            hipMemcpyAsync(c->b_pars, c->b_q0, bytes, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(c->b_grad, c->b_g0, bytes, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(bad, bad0, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s);
+            hipStreamSynchronize(s);
+            c->b_last_grad = false;
+            c->b_traj_ready = false;
+            return rc;
+        }
         hmc_status(s, c->b_info, c->b_scal, bad, fl, B);
         const bool last = step == nsteps - 1;
         hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, last ? 0.5 * eps : eps, eps, last ? 0 : 1, P, B);
@@ -1313,29 +1330,42 @@ extern "C" int nmgp_profile_read(nmgp_ctx* c, double ms[NMGP_STAGE_COUNT], long 
     return 0;
 }
 
-extern "C" int nmgp_measure_hbm_gbs(nmgp_ctx* c, long long bytes, int reps, double* gbs) {
+// HBM ceilings of this chip as the library's own streaming kernels see them (flat 16-byte-per-lane kernels over buffers far
+// beyond the 256 MiB Infinity Cache): gbs3 = {copy (read + write bytes), read only, write only} in GB/s.
+extern "C" int nmgp_measure_hbm_rates(nmgp_ctx* c, long long bytes, int reps, double gbs3[3]) {
     if (!c) return NMGP_E_NULL;
-    if (!gbs) return nmgp_fail(c, NMGP_E_NULL, "gbs must not be NULL");
+    if (!gbs3) return nmgp_fail(c, NMGP_E_NULL, "gbs3 must not be NULL");
     if (bytes < 1024 || reps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "bytes/reps too small");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nelem = ((size_t)bytes / 16) * 2;
     double *src, *dst;
     NMGP_TRY(nmgp_scratch_get(c, 3, nelem, &src));
-    NMGP_TRY(nmgp_scratch_get(c, 4, nelem, &dst));
+    NMGP_TRY(nmgp_scratch_get(c, 4, nelem + 512, &dst));
+    double* sink = dst + nelem;
     HIP_TRY(c, hipMemsetAsync(src, 0, nelem * sizeof(double), c->stream));
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
-    stream_copy(c->stream, src, dst, nelem);
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
-    for (int r = 0; r < reps; ++r) stream_copy(c->stream, src, dst, nelem);
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    for (int mode = 0; mode < 3; ++mode) {
+        stream_copy(c->stream, src, dst, nelem, mode, sink);
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps; ++r) stream_copy(c->stream, src, dst, nelem, mode, sink);
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+        gbs3[mode] = (mode == 0 ? 2.0 : 1.0) * (double)nelem * 8.0 * reps / (ms * 1e-3) / 1e9;
+    }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    *gbs = 2.0 * (double)nelem * 8.0 * reps / (ms * 1e-3) / 1e9;   // read + write
+    return nmgp_take_launch_error(c);
+}
+
+extern "C" int nmgp_measure_hbm_gbs(nmgp_ctx* c, long long bytes, int reps, double* gbs) {
+    if (!gbs) return c ? nmgp_fail(c, NMGP_E_NULL, "gbs must not be NULL") : NMGP_E_NULL;
+    double g3[3];
+    NMGP_TRY(nmgp_measure_hbm_rates(c, bytes, reps, g3));
+    *gbs = g3[0];
     return 0;
 }
 

@@ -508,6 +508,7 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
         NmgpStage sp(c, NMGP_STAGE_COV);
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:258
     }, hs, &loglik, &ck, &attempts));
+    c->last_sep_attempts = attempts;
     // GP priors on tilde_l and tilde_sigma (logpos.py:271-281): solved on the prior stream under the likelihood
     double q[2], hl[2];
     {
@@ -587,6 +588,7 @@ extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyp
         NmgpStage sp(c, NMGP_STAGE_COV);
         gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);   // logpos.py:429
     }, hs, &loglik, &ck, &attempts));
+    c->last_sep_attempts = attempts;
     double dl = 0.0, lp_l = 0.0, lp_uL = 0.0, lp_s2 = 0.0;
     std::vector<double> g_uL_prior(T, 0.0);
     // the reference only evaluates the prior terms when Prior is true (logpos.py:445-458)
@@ -844,6 +846,11 @@ static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, c
                               N, &zero, proj, S));
     return 0;
 }
+
+// 0: the last separable / stationary evaluation is that of the exact covariance; k > 0: value and gradient belong to the
+// covariance with k x 1e-6 added to the diagonals of B and K_x (the deterministic stand-in for the reference's random-jitter
+// retry, logpos.py:267-268)
+extern "C" int nmgp_last_sep_attempts(const nmgp_ctx* c) { return c ? c->last_sep_attempts : -1; }
 
 extern "C" int nmgp_predict_svc(nmgp_ctx* c, const double* pars, const double hyper[8], const double* xs, int S,
                                 double* mean, double* var, double* Lstar) {

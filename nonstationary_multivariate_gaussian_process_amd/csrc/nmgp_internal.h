@@ -139,6 +139,7 @@ struct nmgp_ctx {
     double* b_x = nullptr;      // [B, N]
     double* b_y = nullptr;      // [B, n] output-major
     std::vector<PriorFactor> b_priors;   // L: [B] x (ld x N), logdet: [B]
+    int last_sep_attempts = 0;  // jitter retries the last separable / stationary evaluation needed (0 = the exact covariance)
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
 
@@ -195,8 +196,12 @@ struct NmgpStage {   // RAII HIP-event timer of one stage on the context's strea
 // API boundary.
 void nmgp_note_launch_error(const char* kernel, hipError_t e);
 int nmgp_take_launch_error(nmgp_ctx* c);
+// (An error left behind by an EARLIER runtime call whose status was dropped -- an event record, a library internal -- is
+// taken off first and recorded under its own label, so that it is not pinned on this kernel.)
 #define NMGP_LAUNCH(kern, ...)                                             \
     do {                                                                   \
+        hipError_t pe__ = hipGetLastError();                               \
+        if (pe__ != hipSuccess) nmgp_note_launch_error("(an earlier HIP call, noticed before " #kern ")", pe__); \
         hipLaunchKernelGGL(kern, __VA_ARGS__);                             \
         hipError_t le__ = hipGetLastError();                               \
         if (le__ != hipSuccess) nmgp_note_launch_error(#kern, le__);       \
@@ -273,7 +278,7 @@ void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch = 1);
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
 void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l, double mu_L, double* R, int ld,
                    int batch = 1);
-void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem);
+void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem, int mode = 0, double* sink = nullptr);
 void adam_step(hipStream_t s, double* par, const double* g, double* m, double* v, int* alive, const int* info, const double* scal,
                double b1, double b2, double bc2s, double eps, double step, long long P, int B);
 void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B);

@@ -571,15 +571,31 @@ void svc_prior_rhs(hipStream_t s, const double* pars, int N, int T, double mu_l,
     NMGP_LAUNCH(k_svc_prior_rhs, dim3(cdiv(N, 256), batch), dim3(256), 0, s, pars, N, T, mu_l, mu_L, R, ld);
 }
 
-// HBM stream micro-benchmark (16 B per lane)
-__global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ src, double2* __restrict__ dst,
-                                                      size_t n2) {
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n2; k += stride) dst[k] = src[k];
+// HBM stream micro-benchmarks (16 B per lane).  Shape found with tools/lab/hbm_lab.hip on MI355X: a FLAT grid -- one chunk of
+// 256 x 16 bytes per workgroup, no grid-stride loop -- reaches 6.2 TB/s for a copy, 6.7 TB/s read-only (7.0 with nontemporal
+// loads) and 6.9 TB/s write-only; the same kernels as persistent grid-stride loops (the round-1/2 form, 2048 workgroups) stay
+// at 4.7-5.4 TB/s.  MODE 0: copy, 1: read only, 2: write only.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_stream(const double2* __restrict__ src, double2* __restrict__ dst, size_t n2, double* __restrict__ sink) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n2) return;
+    if (MODE == 0) {
+        dst[k] = src[k];
+    } else if (MODE == 1) {
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(src) + k);
+        if (v[0] + v[1] == 1.2345e300) sink[threadIdx.x] = v[0];    // never true for the zero-filled source: keeps the load alive
+    } else {
+        dst[k] = make_double2(1.5, 2.5);
+    }
 }
 
-void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem) {
-    NMGP_LAUNCH(k_stream_copy, dim3(256 * 8), dim3(256), 0, s, (const double2*)src, (double2*)dst, nelem / 2);
+void stream_copy(hipStream_t s, const double* src, double* dst, size_t nelem, int mode, double* sink) {
+    const size_t n2 = nelem / 2;
+    const dim3 grid((unsigned)((n2 + 255) / 256));
+    if (mode == 0) NMGP_LAUNCH(k_stream<0>, grid, dim3(256), 0, s, (const double2*)src, (double2*)dst, n2, sink);
+    else if (mode == 1) NMGP_LAUNCH(k_stream<1>, grid, dim3(256), 0, s, (const double2*)src, (double2*)dst, n2, sink);
+    else NMGP_LAUNCH(k_stream<2>, grid, dim3(256), 0, s, (const double2*)src, (double2*)dst, n2, sink);
 }
 
 

@@ -115,6 +115,14 @@ def map_stationary(x, Y, pars0, hyper_pars, N_opt=1000, lr=1e-1, verbose=False):
     return torch.cat([tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err.view(1)]).detach().numpy().copy(), hist
 
 
+def valid_rows(out, status):
+    """ONE validity predicate for every lock-step driver, host- or device-resident: an evaluation counts when the factorisation
+    succeeded (status 0) and both the log posterior and the likelihood are finite -- what k_alive_update / k_hmc_status test on the
+    device (nmgp_kernels.hip) and nmgp_svc_batch_fetch folds into the status it returns."""
+    out = np.asarray(out)
+    return (np.asarray(status) == 0) & np.isfinite(out[:, 0]) & np.isfinite(out[:, 1])
+
+
 class LockStepMAP:
     """MAP by Adam for B independent subjects (or B restarts of one subject) advanced in lock-step: every iteration asks
     ``value_and_grad(P [B, P])`` for the verbose tuples [B, 5], the gradients d NegLog / d pars [B, P] and a status [B] of ALL
@@ -139,7 +147,7 @@ class LockStepMAP:
 
     def step(self):
         out, grad, status = self.value_and_grad(self.P)
-        ok = self.alive & (np.asarray(status) == 0) & np.isfinite(out[:, 0])
+        ok = self.alive & valid_rows(out, status)
         self.alive = ok
         self.t += 1
         bc1 = 1.0 - self.b1 ** self.t
@@ -293,7 +301,8 @@ class HMCSampler:
                 H1 = U1 + self.kinetic(p1)
             except RuntimeError:                  # covariance left the positive definite cone: reject
                 U1, H1 = np.inf, np.inf
-            dH = H1 - H0
+            with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
+                dH = H1 - H0
             u = np.log(self.rng.random())         # drawn every iteration: the stream does not depend on the outcome
             acc = bool(np.isfinite(dH) and (u < -dH))
             if acc:
@@ -359,7 +368,8 @@ class LockStepHMC:
                 p1 = p1 - (self.eps if step < self.L - 1 else 0.5 * self.eps) * g1
             U1 = np.where(failed, np.inf, U1)
             H1 = U1 + 0.5 * (p1 * p1).sum(1)
-            dH = H1 - H0
+            with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
+                dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])
             acc = np.isfinite(dH) & (u < -dH)
             self.q[acc] = q1[acc]
@@ -408,7 +418,7 @@ class BatchedHMC(LockStepHMC):
         out, status = self.ctx.svc_batch_fetch()
         g = self.ctx.svc_batch_fetch_grad()
         U = out[:, 0].copy()
-        bad = status != 0
+        bad = ~valid_rows(out, status)
         U[bad] = np.inf
         g[bad] = 0.0
         return U, g
@@ -432,7 +442,8 @@ class BatchedHMC(LockStepHMC):
             q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
             U1 = np.where(failed, np.inf, U1)
             H1 = U1 + 0.5 * (p1 * p1).sum(1)
-            dH = H1 - H0
+            with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
+                dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])
             acc = np.isfinite(dH) & (u < -dH)
             self.ctx.svc_batch_traj_commit(acc)

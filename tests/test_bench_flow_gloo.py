@@ -129,7 +129,11 @@ def test_chain_workload_two_ranks():
     cfg = rec["config"]
     assert cfg["chains_total"] == 2 * B and cfg["chains_ok"] == 2 * B and cfg["chains_failed"] == 0
     assert cfg["chain_table_rows"] == 2 * B
-    assert "cpu_baseline" not in rec                       # rank 0 at N = 1 only
+    assert "cpu_baseline" not in rec and "single-GPU" in rec["cpu_baseline_note"]       # rank 0 at N = 1 only, and the line says so
+    dr = rec["distributed"]                                # first-contact diagnostics of a multi-GPU run
+    assert dr["process_group"] == {"backend": "gloo", "world_size": 2, "rank": 0} and dr["world_size_env"] == 2
+    assert len(dr["ms_per_step_by_rank"]) == 2 and dr["ms_per_step_min_rank"] <= dr["ms_per_step_max_rank"]
+    assert abs(dr["ms_per_step_max_rank"] - rec["ms_per_step"]) < 1e-9 * rec["ms_per_step"]      # the headline is the slowest rank
     assert rec["grad"]["steps"] == gsteps and rec["grad"]["chains_ok"] == B and rec["grad"]["value"] > 0
     # warm-up + timed + (no profiling pass on this backend) + grad warm-up + grad steps
     assert got[0][4] == [warm + steps + 1 + gsteps] and got[1][4] == [warm + steps + 1 + gsteps]
@@ -160,6 +164,8 @@ def test_subject_workload_two_ranks():
     rec = json.loads([ln for ln in got[0][1].splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 2 and rec["config"]["subjects_total"] == 6 and rec["config"]["subjects_ok"] == 6
     assert rec["config"]["subject_table_rows"] == 6
+    assert rec["distributed"]["process_group"]["world_size"] == 2 and len(rec["distributed"]["ms_per_step_by_rank"]) == 2
+    assert "cpu_baseline_note" in rec and rec["roofline"]["traffic"] is None and "no committed PMC" in rec["roofline"]["traffic_note"]
     table = got[0][3]
     assert np.array_equal(table, got[1][3]) and list(table[:, 0]) == list(range(6))
     sys.path.insert(0, ROOT)

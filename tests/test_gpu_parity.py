@@ -180,13 +180,14 @@ def test_sep_against_reference_golden(ctx, name):
     out, grad = ctx.logpos_sep(g["pars"], g["hyper"], prior=bool(g["prior"]), want_grad=True)
     N = g["Y"].shape[0]
     record_parity(name, neglog=(relerr(out[0], g["out"][0]), VAL_TOL), loglik=(relerr(out[1], g["out"][1]), 1e-8),
-                  priors=(prior_term_err(out[2:4], g["out"][2:4], N), VAL_TOL), grad=(vec_relerr(grad, g["grad"]), 1e-4))
+                  priors=(prior_term_err(out[2:4], g["out"][2:4], N), VAL_TOL), grad=(vec_relerr(grad, g["grad"]), GRAD_TOL))
     assert relerr(out[0], g["out"][0]) < VAL_TOL, (out, g["out"])
     assert relerr(out[1], g["out"][1]) < 1e-8          # eigen-trick likelihood
     assert prior_term_err(out[2:4], g["out"][2:4], N) < VAL_TOL and relerr(out[4:], g["out"][4:]) < VAL_TOL
     assert relerr(out[4], g["out"][4]) < 1e-13         # Normal(0, c) incl. the float32 log(c) quirk
-    # the reference backpropagates through eigh (noisy at the jitter floor); ours is the analytic adjoint
-    assert vec_relerr(grad, g["grad"]) < 1e-4
+    # the reference backpropagates through eigh, ours is the analytic adjoint; achieved: <= 6e-7 up to N = 512, 4.9e-6 at
+    # N = 4096 (the GP-prior part, conditioning-bound: DESIGN.md section 5) -- the same 1e-5 bar as the nonseparable gradient
+    assert vec_relerr(grad, g["grad"]) < GRAD_TOL
     out2, _ = ctx.logpos_sep(g["pars"], g["hyper"], prior=bool(g["prior"]), want_grad=False)
     assert relerr(out2, out) < 1e-13
 
@@ -214,9 +215,9 @@ def test_sta_against_reference_golden(ctx, name):
     ctx.set_data(g["x"], g["Y"])
     out, grad = ctx.logpos_sta(g["pars"], g["hyper"], prior=True, want_grad=True)
     record_parity(name, neglog=(relerr(out[0], g["out"][0]), 1e-8), components=(relerr(out, g["out"]), 1e-8),
-                  grad=(vec_relerr(grad, g["grad"]), 1e-4))
+                  grad=(vec_relerr(grad, g["grad"]), 1e-8))
     assert relerr(out, g["out"]) < 1e-8, (out, g["out"])
-    assert vec_relerr(grad, g["grad"]) < 1e-4
+    assert vec_relerr(grad, g["grad"]) < 1e-8          # achieved <= 1e-10 (no GP prior in this model)
     from oracle import nmgp_oracle as O
     ref, gref = O.nlogpos_obj_S(g["pars"], g["Y"], g["x"], **hyper_dict(g["hyper"], STA_KEYS), verbose=True, grad=True)
     assert vec_relerr(grad, gref) < 1e-7
@@ -252,7 +253,7 @@ def test_python_mirror_sep_sta_and_primitives(ctx):
     out = U.logpos.nlogpos_obj(p, torch.from_numpy(g["Y"]), torch.from_numpy(g["x"]), **h, verbose=True)
     assert len(out) == 6 and relerr([float(o.detach()) for o in out], g["out"]) < VAL_TOL
     out[0].backward()
-    assert vec_relerr(p.grad.numpy(), g["grad"]) < 1e-4
+    assert vec_relerr(p.grad.numpy(), g["grad"]) < GRAD_TOL
     g = golden("sta_rngfree_N64_M3")
     h = hyper_dict(g["hyper"], STA_KEYS)
     p = torch.from_numpy(g["pars"]).clone().requires_grad_(True)
@@ -260,7 +261,7 @@ def test_python_mirror_sep_sta_and_primitives(ctx):
                                  h["sigma_tilde_l"], a=h["a"], b=h["b"], c=h["c"], verbose=True)
     assert len(out) == 5 and relerr([float(o.detach()) for o in out], g["out"]) < 1e-8
     out[0].backward()
-    assert vec_relerr(p.grad.numpy(), g["grad"]) < 1e-4
+    assert vec_relerr(p.grad.numpy(), g["grad"]) < 1e-8
     gp = golden("prims")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     assert np.allclose(U.kronecker_operation.kron_mv(t(gp["Br"]), t(gp["Kr"]), t(gp["yr"])).numpy(), gp["kron_mv_rect"])
@@ -380,6 +381,33 @@ def test_prediction_many_grid_points_on_a_fresh_context():
                                             h["mu_L"], h["alpha_L"], h["beta_L"])
     assert np.allclose(mean, mo, rtol=1e-5, atol=1e-7) and np.allclose(var, vo, rtol=1e-5, atol=1e-9)
     assert np.allclose(Ls, Lo, rtol=1e-6, atol=1e-6)
+
+
+def test_batch_with_two_different_prior_factors_equals_single_chain_evaluations(ctx):
+    """Chains of ONE subject whose GP priors on l~ and on uL have different hyper-parameters (the reference's _distributed
+    scripts: alpha 5, beta_tilde_l 0.1, beta_L 0.2, Nonseparable_model_distributed.py:47-48) share two prior factors: the batch
+    solves them with two strided-batched calls (factor stride 0).  Every chain must reproduce its single-chain evaluation."""
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    N, M, B = 160, 3, 5
+    d = sim.simulate_nonseparable(N, M, seed=11)
+    hv = np.array([0.0, 5.0, 0.1, 0.0, 5.0, 0.2, 1.0, 1.0])
+    allp = np.stack([sim.perturb(d["pars_true"], 0.05, 0.3 + 0.5 * b) for b in range(B)])
+    ctx.set_data(d["x"], d["Y"])
+    singles = [ctx.logpos_svc(allp[b], hv, prior=True, want_grad=True) for b in range(B)]
+    c = _lib.Context(0)
+    try:
+        c.set_data(d["x"], d["Y"])
+        c.svc_batch_alloc(B)
+        c.svc_batch_set_pars(allp)
+        c.svc_batch_eval(hv, True, True)
+        out, st = c.svc_batch_fetch()
+        grads = c.svc_batch_fetch_grad()
+    finally:
+        c.close()
+    assert np.all(st == 0)
+    for b in range(B):
+        assert relerr(out[b], singles[b][0]) < 1e-11, (b, out[b], singles[b][0])
+        assert vec_relerr(grads[b], singles[b][1]) < 1e-10
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -631,7 +659,7 @@ def test_config5_separable_N4096_D5_both_formulations_against_reference_golden()
         res[algo] = (out, grad)
         errs = dict(neglog=(relerr(out[0], g["out"][0]), VAL_TOL), loglik=(relerr(out[1], g["out"][1]), 1e-8),
                     priors=(prior_term_err(out[2:4], g["out"][2:4], N), VAL_TOL),
-                    grad=(vec_relerr(grad, g["grad"]), 1e-4), value_only_vs_grad_path=(relerr(out_v, out), 1e-11))
+                    grad=(vec_relerr(grad, g["grad"]), GRAD_TOL), value_only_vs_grad_path=(relerr(out_v, out), 1e-11))
         record_parity("sep_sim_N4096_M5_" + algo, **errs)
         for k, (e, tol) in errs.items():
             assert e < tol, (algo, k, e, tol, out, g["out"])
@@ -710,6 +738,7 @@ def test_separable_and_stationary_objectives_recover_from_a_singular_covariance(
     # Prior=False: with sigma2_err = 0 the inverse-gamma prior term is inf - inf in the reference too; the likelihood is the point
     out, grad = ctx.logpos_sep(pars, hv, prior=False, want_grad=True)
     assert np.all(np.isfinite(out[:2])) and out[0] == -out[1] and np.all(np.isfinite(grad))
+    assert ctx.last_sep_attempts() == 1          # the caller can tell: value and gradient are those of the jittered covariance
     # the likelihood of attempt 1: B + 1e-6 I, K + 1e-6 I
     Lm = O.vec2lowtriangle(O.uLvec2Lvec(uL, M), M)
     Bf = Lm @ Lm.T + 1e-6 * np.eye(M)
@@ -723,6 +752,7 @@ def test_separable_and_stationary_objectives_recover_from_a_singular_covariance(
     ctx.set_data(g["x"], g["Y"])
     o2, _ = ctx.logpos_sep(g["pars"], g["hyper"], True, False)
     assert relerr(o2[0], g["out"][0]) < VAL_TOL
+    assert ctx.last_sep_attempts() == 0
 
 
 def test_repeated_evaluations_are_bit_identical_on_the_multi_stream_schedules(ctx):

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -95,6 +96,42 @@ __global__ __launch_bounds__(256) void k_write8(double* __restrict__ dst, size_t
     }
 }
 
+// ---- shaped access: a workgroup owns an R-row x CN-column block of a column-major matrix (leading dimension ld), i.e. CN
+// segments of 8 R contiguous bytes, a column apart -- the shape of the panel kernels (k_trsm_64f: R = 128, CN = 64; the update
+// kernel's C tile: 128 x 128; k_svc_cov: 64-row segments).  MODE 0: write, 1: read-modify-write in place, 2: read only.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shaped(double* __restrict__ A, int ld, int rows, int R, int CN, double* __restrict__ sink) {
+    // blockIdx.x = row block (fastest, as in the library's launches), blockIdx.y = column block
+    const int r0 = blockIdx.x * R, c0 = blockIdx.y * CN;
+    const int pairs = R / 2;                        // 16-byte accesses per column segment
+    const int per_col = pairs;                      // threads needed per column
+    const int cols_par = 256 / per_col > 0 ? 256 / per_col : 1;     // columns handled concurrently
+    double acc = 0.0;
+    if (per_col <= 256) {
+        const int cl = threadIdx.x / per_col, pr = threadIdx.x % per_col;
+        if (cl < cols_par)
+            for (int c = cl; c < CN; c += cols_par) {
+                v2d* p = reinterpret_cast<v2d*>(A + (size_t)(c0 + c) * ld + r0 + 2 * pr);
+                if (r0 + 2 * pr + 1 < rows) {
+                    if (MODE == 0) *p = v2d{1.5, 2.5};
+                    else if (MODE == 1) { v2d v = *p; v[0] = v[0] * 1.0000001; v[1] = v[1] + 1.0; *p = v; }
+                    else { v2d v = *p; acc += v[0] + v[1]; }
+                }
+            }
+    } else {
+        for (int c = 0; c < CN; ++c)
+            for (int pr = threadIdx.x; pr < pairs; pr += 256) {
+                v2d* p = reinterpret_cast<v2d*>(A + (size_t)(c0 + c) * ld + r0 + 2 * pr);
+                if (r0 + 2 * pr + 1 < rows) {
+                    if (MODE == 0) *p = v2d{1.5, 2.5};
+                    else if (MODE == 1) { v2d v = *p; v[0] = v[0] * 1.0000001; v[1] = v[1] + 1.0; *p = v; }
+                    else { v2d v = *p; acc += v[0] + v[1]; }
+                }
+            }
+    }
+    if (MODE == 2 && acc == 1.2345e300) sink[threadIdx.x] = acc;
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() {
@@ -145,6 +182,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(src, 0, n2 * 16));
     CK(hipMemset(dst, 0, n2 * 16));
     Timer T;
+    const bool shaped_only = argc > 2 && std::string(argv[2]) == "shaped";
+    if (!shaped_only) {
     sweep<1, false>(T, src, dst, sink, n2, ncu);
     sweep<2, false>(T, src, dst, sink, n2, ncu);
     sweep<4, false>(T, src, dst, sink, n2, ncu);
@@ -161,6 +200,28 @@ int main(int argc, char** argv) {
             const double t8 = T.run([&] { hipLaunchKernelGGL((k_write8<8>), dim3(g8), dim3(256), 0, 0, (double*)dst, n, 2.5); }, 5);
             std::printf("8-byte stores wpc=%-4s U=4 %7.1f  U=8 %7.1f GB/s\n", wpc ? std::to_string(wpc).c_str() : "flat",
                         bytes / t4 / 1e9, bytes / t8 / 1e9);
+        }
+    }
+    }
+    // shaped access over a batch of column-major matrices: 6144 rows, ld 6160, 96 matrices x 64 columns per launch (as one panel
+    // solve of the 128-chain batch... scaled to fill 1 GiB: columns = as many as fit)
+    {
+        const int rows = 6144, ld = 6160;
+        const size_t total = n2 * 2;                     // doubles in dst
+        const int cols = (int)(total / ld);
+        double* A = (double*)dst;
+        std::printf("shaped: %d rows (ld %d) x %d columns\n", rows, ld, cols);
+        const int Rs[] = {64, 128, 256, 512, 1024, 2048, 6144};
+        for (int R : Rs) {
+            const int CN = 8192 / R > 0 ? 8192 / R : 1;  // 64 KB per workgroup
+            const dim3 grid((rows + R - 1) / R, cols / CN);
+            const double bytes = (double)rows * 8.0 * (double)(grid.y * CN);
+            const double tw = T.run([&] { hipLaunchKernelGGL((k_shaped<0>), grid, dim3(256), 0, 0, A, ld, rows, R, CN, sink); }, 5);
+            const double tm = T.run([&] { hipLaunchKernelGGL((k_shaped<1>), grid, dim3(256), 0, 0, A, ld, rows, R, CN, sink); }, 5);
+            const double tr = T.run([&] { hipLaunchKernelGGL((k_shaped<2>), grid, dim3(256), 0, 0, A, ld, rows, R, CN, sink); }, 5);
+            std::printf("R=%-5d CN=%-4d segment %6d B   write %7.1f   read+write in place %7.1f   read %7.1f GB/s\n", R, CN, R * 8,
+                        bytes / tw / 1e9, 2.0 * bytes / tm / 1e9, bytes / tr / 1e9);
+            std::fflush(stdout);
         }
     }
     // hipMemcpyAsync device-to-device and hipMemsetAsync for reference
