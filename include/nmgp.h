@@ -111,8 +111,14 @@ double* nmgp_svc_batch_grad_dev(nmgp_ctx* ctx);
  *   nmgp_svc_batch_traj_begin : after a batched value+gradient evaluation of the start positions (set_pars + batch_eval(.., 1))
  *   nmgp_svc_batch_traj       : p0 [B,P] in; end point q1, p1 [B,P], potential U1 [B] (NegLog; +inf where failed) and
  *                               failed [B] (1: the potential was undefined somewhere on the trajectory -> reject) out
- *   nmgp_svc_batch_traj_commit: accept [B]; rejected chains get their pre-trajectory position and gradient back */
+ *   nmgp_svc_batch_traj_commit: accept [B]; rejected chains get their pre-trajectory position and gradient back
+ *   nmgp_svc_batch_traj_set_mass: constant mass matrix M of the sampler (Nonseparable_model_mpiKAISER.py:267-270,398-411 passes
+ *                               M = inv(sample covariance), step size 1e-1, 5 leapfrog steps): kind 0 identity (default),
+ *                               1 diagonal (minv = diag(M^-1) [P]), 2 dense (minv = M^-1 [P,P], row-major == column-major: it is
+ *                               symmetric).  The drift becomes q += eps M^-1 p (dense: one GEMM per leapfrog step for all chains);
+ *                               momenta p ~ N(0, M) and the kinetic energy 1/2 p^T M^-1 p remain the caller's. */
 int nmgp_svc_batch_traj_begin(nmgp_ctx* ctx);
+int nmgp_svc_batch_traj_set_mass(nmgp_ctx* ctx, int kind, const double* minv);
 int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
                         double* q1, double* p1, double* U1, int* failed);
 int nmgp_svc_batch_traj_commit(nmgp_ctx* ctx, const int* accept);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nmgp_svc_batch_grad_dev": (V, [V]),
     "nmgp_svc_batch_fetch": (I, [V, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_begin": (I, [V]),
+    "nmgp_svc_batch_traj_set_mass": (I, [V, I, P]),
     "nmgp_svc_batch_traj": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_adam_begin": (I, [V]),
@@ -255,6 +256,21 @@ class Context:
         """After set_pars + batch_eval(want_grad=True) at the start positions: positions and gradients become the state
         the trajectories start from."""
         self.check(self.lib.nmgp_svc_batch_traj_begin(self.h))
+
+    def svc_batch_traj_set_mass(self, minv=None):
+        """Mass matrix of the device-resident trajectories: None (identity), diag(M^-1) [P] or dense M^-1 [P, P]."""
+        if minv is None:
+            self.check(self.lib.nmgp_svc_batch_traj_set_mass(self.h, 0, None))
+            return
+        minv = as_f64(minv)
+        P = self.N * (1 + self.T) + 1
+        if minv.shape == (P,):
+            kind = 1
+        elif minv.shape == (P, P):
+            kind = 2
+        else:
+            raise ValueError("minv must be [P] or [P, P] with P = %d" % P)
+        self.check(self.lib.nmgp_svc_batch_traj_set_mass(self.h, kind, ptr(minv)))
 
     def svc_batch_traj(self, hyper, prior, eps, nsteps, p0):
         """One leapfrog trajectory per chain from the resident state with momenta p0 [B, P]: returns the end point

@@ -652,7 +652,8 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
-                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av};
+                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel};
+    c->b_mass_kind = 0;
     if (c->b_alive) hipFree(c->b_alive);
     c->b_alive = nullptr;
     c->b_adam_t = -1;
@@ -998,8 +999,59 @@ extern "C" int nmgp_svc_batch_traj_begin(nmgp_ctx* c) {
     return nmgp_take_launch_error(c);
 }
 
+// Mass matrix of the device-resident trajectories (the reference's production sampler passes a dense M = inv(sample covariance)
+// with step size 1e-1 and 5 leapfrog steps: Nonseparable_model_mpiKAISER.py:267-270,398-411).  kind 0: identity (default);
+// 1: diagonal, minv = diag(M^-1) [P]; 2: dense, minv = M^-1 [P, P] (symmetric; P = 14,337 at the headline size: 1.6 GB, shared by
+// all chains of the batch).  The device only needs the VELOCITY M^-1 p of the drift q += eps M^-1 p -- one GEMM [P, P] x [P, B] per
+// leapfrog step for all chains; the caller draws the momenta p ~ N(0, M) and evaluates the kinetic energy 1/2 p^T M^-1 p.
+extern "C" int nmgp_svc_batch_traj_set_mass(nmgp_ctx* c, int kind, const double* minv) {
+    if (!c) return NMGP_E_NULL;
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    if (kind < 0 || kind > 2) return nmgp_fail(c, NMGP_E_SHAPE, "mass matrix kind must be 0 (identity), 1 (diagonal) or 2 (dense)");
+    if (kind != 0 && !minv) return nmgp_fail(c, NMGP_E_NULL, "minv must not be NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t P = (size_t)c->P_svc, B = c->batch;
+    if (c->b_minv) hipFree(c->b_minv);
+    if (c->b_vel) hipFree(c->b_vel);
+    c->b_minv = c->b_vel = nullptr;
+    c->b_mass_kind = 0;
+    if (kind == 0) return 0;
+    const size_t nelem = kind == 1 ? P : P * P;
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_minv, nelem));
+    if (kind == 2) NMGP_TRY(nmgp_dev_alloc(c, &c->b_vel, B * P));
+    HIP_TRY(c, hipMemcpyAsync(c->b_minv, minv, nelem * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->b_mass_kind = kind;
+    return 0;
+}
+
+// p -= c g (chains whose gradient is defined), then -- if drift -- q += eps M^-1 p
+static int traj_kick_drift(nmgp_ctx* c, double kick, double eps, int drift) {
+    const int B = c->batch;
+    const long long P = c->P_svc;
+    hipStream_t s = c->stream;
+    int* bad = c->b_hmc;
+    if (c->b_mass_kind == 0) {
+        hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, kick, eps, drift, P, B);
+        return 0;
+    }
+    hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, kick, eps, 0, P, B);
+    if (!drift) return 0;
+    if (c->b_mass_kind == 2) {
+        // V [P x B] = M^-1 [P x P] * momenta [P x B] (the [B, P] row-major block IS column-major [P, B])
+        const double one = 1.0, zero = 0.0;
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (int)P, B, (int)P, &one, c->b_minv,
+                                  (int)P, c->b_mom, (int)P, &zero, c->b_vel, (int)P));
+        hmc_drift(s, c->b_pars, c->b_mom, c->b_vel, nullptr, eps, P, B);
+    } else {
+        hmc_drift(s, c->b_pars, c->b_mom, nullptr, c->b_minv, eps, P, B);
+    }
+    return 0;
+}
+
 // One trajectory for every chain: p0 [B, P] (host) are the momenta drawn by the caller; `nsteps` leapfrog steps of size `eps`
-// with identity mass matrix, one batched value+gradient evaluation per step.  Returns the end point q1, p1 [B, P], the
+// (mass matrix: nmgp_svc_batch_traj_set_mass, identity by default), one batched value+gradient evaluation per step.  Returns the end point q1, p1 [B, P], the
 // potential there U1 [B] and failed [B] = 1 for a chain whose potential was undefined at ANY point of the trajectory (to be
 // rejected).  The device then holds the END state; nmgp_svc_batch_traj_commit puts the rejected chains back.
 extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
@@ -1021,7 +1073,7 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
     HIP_TRY(c, hipMemcpyAsync(c->b_g0, c->b_grad, bytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(bad0, bad, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemsetAsync(fl, 0, (size_t)B * sizeof(int), s));
-    hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, 0.5 * eps, eps, 1, P, B);
+    NMGP_TRY(traj_kick_drift(c, 0.5 * eps, eps, 1));
     for (int step = 0; step < nsteps; ++step) {
         if (int rc = nmgp_svc_batch_eval(c, hyper, prior, 1)) {
             // an API-level failure in the middle of a trajectory (not a chain's numerical failure: those are flags): put the
@@ -1037,7 +1089,7 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
         }
         hmc_status(s, c->b_info, c->b_scal, bad, fl, B);
         const bool last = step == nsteps - 1;
-        hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, last ? 0.5 * eps : eps, eps, last ? 0 : 1, P, B);
+        NMGP_TRY(traj_kick_drift(c, last ? 0.5 * eps : eps, eps, last ? 0 : 1));
     }
     std::vector<double> h((size_t)B * 16);
     HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));

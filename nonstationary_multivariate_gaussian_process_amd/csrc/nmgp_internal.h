@@ -139,6 +139,9 @@ struct nmgp_ctx {
     double* b_x = nullptr;      // [B, N]
     double* b_y = nullptr;      // [B, n] output-major
     std::vector<PriorFactor> b_priors;   // L: [B] x (ld x N), logdet: [B]
+    int b_mass_kind = 0;        // mass matrix of the device-resident trajectories: 0 identity, 1 diagonal, 2 dense (b_minv = M^-1)
+    double* b_minv = nullptr;   // [P] or [P, P]
+    double* b_vel = nullptr;    // [B, P] velocities M^-1 p (dense mass matrix)
     int last_sep_attempts = 0;  // jitter retries the last separable / stationary evaluation needed (0 = the exact covariance)
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
@@ -284,6 +287,7 @@ void adam_step(hipStream_t s, double* par, const double* g, double* m, double* v
 void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B);
 void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
                     long long P, int B);
+void hmc_drift(hipStream_t s, double* q, const double* p, const double* vel, const double* minv_diag, double eps, long long P, int B);
 void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
                  const int* accept, long long P, int B);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,

@@ -451,6 +451,19 @@ __global__ __launch_bounds__(256) void k_hmc_kick_drift(double* __restrict__ p, 
     }
 }
 
+// q += eps * v with v = M^-1 p: `minv_diag` != null: v_i = minv_diag[i] * p_i (diagonal mass matrix, computed here);
+// else v = `vel` [B, P] (dense mass matrix: the caller's GEMM M^-1 P).  Same operation order as the host sampler: t = eps * v; q + t.
+__global__ __launch_bounds__(256) void k_hmc_drift(double* __restrict__ q, const double* __restrict__ p, const double* __restrict__ vel,
+                                                    const double* __restrict__ minv_diag, double eps, long long P) {
+    const int z = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t o = (size_t)z * P + i;
+    const double v = minv_diag ? minv_diag[i] * p[o] : vel[o];
+    const double t = eps * v;
+    q[o] = q[o] + t;
+}
+
 // rejected chains (accept[z] == 0) get the position, gradient and validity flag they had before the trajectory back
 __global__ __launch_bounds__(256) void k_hmc_restore(double* __restrict__ q, double* __restrict__ g, const double* __restrict__ q0,
                                                       const double* __restrict__ g0, int* __restrict__ bad,
@@ -471,6 +484,9 @@ void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, in
 void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
                     long long P, int B) {
     NMGP_LAUNCH(k_hmc_kick_drift, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, p, g, q, bad, c, eps, drift, P);
+}
+void hmc_drift(hipStream_t s, double* q, const double* p, const double* vel, const double* minv_diag, double eps, long long P, int B) {
+    NMGP_LAUNCH(k_hmc_drift, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, q, p, vel, minv_diag, eps, P);
 }
 void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
                  const int* accept, long long P, int B) {

@@ -329,11 +329,12 @@ def sampler(**kw):
 class LockStepHMC:
     """B independent HMC chains advanced in lock-step: every leapfrog step asks ``potential_and_grad(q [B, P])`` for the
     potentials U [B] and gradients [B, P] of ALL chains at once (U = inf marks a chain whose potential is undefined at
-    that point, e.g. a covariance outside the positive definite cone).  Identity mass matrix.  Chain b draws from its own
+    that point, e.g. a covariance outside the positive definite cone).  Constant mass matrix (identity by default, see
+    :meth:`set_mass`).  Chain b draws from its own
     generator in the order of :class:`HMCSampler` (momentum, then the uniform of the accept test), so a chain reproduces
     the single-chain sampler started from the same state.  Subclasses provide ``potential_and_grad``."""
 
-    def __init__(self, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None):
+    def __init__(self, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, M=None, Minv=None):
         self.q = np.array(init_positions, dtype=np.float64, copy=True)
         if self.q.ndim != 2:
             raise ValueError("init_positions must be [B, P]")
@@ -341,6 +342,49 @@ class LockStepHMC:
         self.eps = float(step_size)
         self.L = int(num_steps_in_leap)
         self.rngs = [np.random.default_rng(None if seed is None else seed + b) for b in range(self.B)]
+        self.set_mass(M, Minv)
+
+    def set_mass(self, M=None, Minv=None):
+        """Constant mass matrix shared by the chains (``M`` of the reference's sampler call, Nonseparable_model_mpiKAISER.py:267-270:
+        M = inv(sample covariance)): None = identity, a vector [P] = diagonal, a matrix [P, P] = dense.  ``Minv`` may be given
+        alongside (the reference's caller HAS it: it is the sample covariance) to spare the inversion; momenta are drawn as
+        chol(M) z, the kinetic energy is 1/2 p^T M^-1 p and the drift q += eps M^-1 p."""
+        P = self.P
+        self.mass_kind = 0
+        self.Mchol = self.Minv = None
+        if M is None and Minv is None:
+            return
+        if M is None:
+            Minv = np.asarray(Minv, dtype=np.float64)
+            M = 1.0 / Minv if Minv.ndim == 1 else np.linalg.inv(Minv)
+        M = np.asarray(M, dtype=np.float64)
+        if M.shape == (P,):
+            if np.any(M <= 0):
+                raise ValueError("diagonal mass matrix must be positive")
+            self.mass_kind = 1
+            self.Mchol = np.sqrt(M)
+            self.Minv = 1.0 / M if Minv is None else np.asarray(Minv, dtype=np.float64).reshape(P)
+        elif M.shape == (P, P):
+            self.mass_kind = 2
+            self.Mchol = np.linalg.cholesky(M)
+            self.Minv = np.linalg.inv(M) if Minv is None else np.asarray(Minv, dtype=np.float64).reshape(P, P)
+        else:
+            raise ValueError("mass matrix must be [P] or [P, P] with P = %d" % P)
+
+    def draw_momenta(self):
+        """[B, P]: chain b draws P standard normals from its own generator (the stream of :class:`HMCSampler`), then p = chol(M) z."""
+        z = np.stack([r.standard_normal(self.P) for r in self.rngs])
+        if self.mass_kind == 0:
+            return z
+        return z * self.Mchol if self.mass_kind == 1 else z @ self.Mchol.T
+
+    def velocity(self, p):
+        if self.mass_kind == 0:
+            return p
+        return p * self.Minv if self.mass_kind == 1 else p @ self.Minv          # (M^-1 is symmetric)
+
+    def kinetic(self, p):
+        return 0.5 * (p * self.velocity(p)).sum(1)
 
     def potential_and_grad(self, q):
         raise NotImplementedError
@@ -352,8 +396,8 @@ class LockStepHMC:
         accepted = np.zeros(B)
         energy_err = np.zeros((sample_size, B))
         for it in range(sample_size):
-            p0 = np.stack([r.standard_normal(P) for r in self.rngs])
-            H0 = U + 0.5 * (p0 * p0).sum(1)
+            p0 = self.draw_momenta()
+            H0 = U + self.kinetic(p0)
             q1 = self.q.copy()
             p1 = p0 - 0.5 * self.eps * g
             U1, g1 = U, g
@@ -362,12 +406,12 @@ class LockStepHMC:
             # HMCSampler.leapfrog returns inf at the first non-finite potential.
             failed = np.zeros(B, dtype=bool)
             for step in range(self.L):
-                q1 = q1 + self.eps * p1
+                q1 = q1 + self.eps * self.velocity(p1)
                 U1, g1 = self.potential_and_grad(q1)
                 failed |= ~np.isfinite(U1)
                 p1 = p1 - (self.eps if step < self.L - 1 else 0.5 * self.eps) * g1
             U1 = np.where(failed, np.inf, U1)
-            H1 = U1 + 0.5 * (p1 * p1).sum(1)
+            H1 = U1 + self.kinetic(p1)
             with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
                 dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])
@@ -387,14 +431,16 @@ class BatchedHMC(LockStepHMC):
     Every leapfrog step evaluates the potential and its gradient for ALL chains with one batched launch sequence
     (``nmgp_svc_batch_eval(want_grad=1)``): the chains are the reference's embarrassingly-parallel unit
     (one process each there, ``Nonseparable_model_mpisim.py:305-306``); here they share the GPU's launch latency.
-    Nonseparable model only (the batched entry point of the C ABI).  Identity mass matrix.
+    Nonseparable model only (the batched entry point of the C ABI).  ``M`` / ``Minv``: constant mass matrix shared by the
+    chains (None: identity; [P]: diagonal; [P, P]: dense, as the reference's production sampler passes it,
+    Nonseparable_model_mpiKAISER.py:267-270,398-411) -- resident on the device, the drift of every leapfrog step is one GEMM.
     ``x`` [N], ``Y`` [N, M]: B chains of one subject; ``x`` [B, N], ``Y`` [B, N, M]: one chain per subject.
     """
 
     def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
-                 device_resident=True):
+                 device_resident=True, M=None, Minv=None):
         from . import _lib
-        super().__init__(init_positions, step_size, num_steps_in_leap, seed)
+        super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
         self.device_resident = bool(device_resident)
         self.ctx = ctx if ctx is not None else _lib.default_context()
         keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
@@ -433,15 +479,16 @@ class BatchedHMC(LockStepHMC):
         B, P = self.B, self.P
         samples = np.zeros((sample_size, B, P))
         U, _ = self.potential_and_grad(self.q)           # leaves q and dU/dq resident
+        self.ctx.svc_batch_traj_set_mass(None if self.mass_kind == 0 else self.Minv)
         self.ctx.svc_batch_traj_begin()
         accepted = np.zeros(B)
         energy_err = np.zeros((sample_size, B))
         for it in range(sample_size):
-            p0 = np.stack([r.standard_normal(P) for r in self.rngs])
-            H0 = U + 0.5 * (p0 * p0).sum(1)
+            p0 = self.draw_momenta()
+            H0 = U + self.kinetic(p0)
             q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
             U1 = np.where(failed, np.inf, U1)
-            H1 = U1 + 0.5 * (p1 * p1).sum(1)
+            H1 = U1 + self.kinetic(p1)
             with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
                 dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])

@@ -105,6 +105,37 @@ def test_lockstep_chains_reject_a_trajectory_that_left_the_domain_cpu():
 
 
 
+def test_lockstep_hmc_with_a_mass_matrix_follows_the_single_chain_sampler_cpu():
+    """LockStepHMC with a diagonal and with a dense constant mass matrix (the reference's production sampler passes
+    M = inv(sample covariance), Nonseparable_model_mpiKAISER.py:267-270,398-411) against HMCSampler(M=...) chain by chain on a
+    Gaussian target, same random streams: momenta chol(M) z, kinetic energy 1/2 p^T M^-1 p, drift q += eps M^-1 p."""
+    from nonstationary_multivariate_gaussian_process_amd.drivers import HMCSampler, LockStepHMC
+    rng = np.random.default_rng(5)
+    P, B, S = 7, 3, 30
+    G = rng.standard_normal((P, P))
+    A = G @ G.T / P + 0.5 * np.eye(P)
+    b = rng.standard_normal(P)
+    W = rng.standard_normal((P, P))
+    masses = {"diag": np.exp(rng.standard_normal(P)), "dense": W @ W.T / P + np.eye(P)}
+    init = rng.standard_normal((B, P))
+
+    class Gauss(LockStepHMC):
+        def potential_and_grad(self, q):
+            r = q - b
+            return 0.5 * np.einsum("bi,ij,bj->b", r, A, r), r @ A
+
+    for kind, Mm in masses.items():
+        ls = Gauss(init, step_size=0.2, num_steps_in_leap=6, seed=21, M=Mm)
+        samples, info = ls.run(S)
+        assert 0.5 < info["accept_rate"].mean() <= 1.0
+        for c in range(B):
+            hs = HMCSampler(sample_size=S, potential_func=_gauss_potential(A, b), init_position=init[c], step_size=0.2,
+                            num_steps_in_leap=6, M=(np.diag(Mm) if kind == "diag" else Mm), seed=0)
+            hs.rng = np.random.default_rng(21 + c)
+            single, _ = hs.main_hmc_loop()
+            assert np.allclose(single, samples[:, c], rtol=1e-10, atol=1e-12), kind
+
+
 @pytest.mark.gpu
 def test_map_trajectory_matches_reference_fixture():
     """100 Adam steps (lr 0.2) from the RNG-free start: the reference's target_value_hist (tests/golden/map_svc_N64_M3,
@@ -206,6 +237,49 @@ def test_device_resident_trajectories_equal_the_host_lock_step_loop_bit_for_bit(
         rates.append(idv["accept_rate"][[0, 1, 2, 4]])
     rates = np.concatenate(rates)
     assert rates.max() == 1.0 and rates.min() < 1.0, rates          # accepted and rejected proposals both occurred
+
+
+@pytest.mark.gpu
+def test_batched_hmc_with_a_mass_matrix_on_the_device():
+    """nmgp_svc_batch_traj_set_mass: the drift of the device-resident trajectories becomes q += eps M^-1 p -- elementwise for a
+    diagonal mass matrix (bit-identical to the host lock-step loop), one GEMM per leapfrog step for a dense one (rounding-level
+    agreement) -- and every chain follows HMCSampler(M=...) started from the same state with the same random stream."""
+    from nonstationary_multivariate_gaussian_process_amd.Utility import logpos
+    from nonstationary_multivariate_gaussian_process_amd.drivers import BatchedHMC, HMCSampler
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    g = golden("svc_rngfree_N32_M2")
+    h = hyper_dict(g["hyper"], SVC_KEYS)
+    B, S, L = 3, 4, 6
+    init = np.stack([sim.perturb(g["pars"], 0.01 * b, 0.5 * b) for b in range(B)])
+    P = init.shape[1]
+    rng = np.random.default_rng(8)
+    W = rng.standard_normal((P, 4))
+    dense = 1e4 * (np.eye(P) + 0.3 * W @ W.T / 4)                  # M ~ 1e4: velocities 1e-2 p, so the step can be 100 x larger
+    diag = 1e4 * np.exp(0.5 * rng.standard_normal(P))
+    x, Y = torch.from_numpy(g["x"]), torch.from_numpy(g["Y"])
+    for kind, Mm in (("diag", diag), ("dense", dense)):
+        dev = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm)
+        sd, idv = dev.run(S)
+        host = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm, device_resident=False)
+        sh, ih = host.run(S)
+        assert np.all(idv["accept_rate"] >= 0.5) and np.nanmax(np.abs(idv["energy_error"])) < 1.0
+        assert not np.allclose(sd[-1], init)                        # the chains moved
+        if kind == "diag":
+            assert np.array_equal(sd, sh) and np.array_equal(idv["energy_error"], ih["energy_error"])
+        else:
+            assert np.allclose(sd, sh, rtol=1e-10, atol=1e-12)
+        for b in range(B):
+            hs = HMCSampler(sample_size=S, potential_func=logpos.nlogpos_obj_SVC, init_position=init[b], step_size=5e-3,
+                            num_steps_in_leap=L, M=(np.diag(Mm) if kind == "diag" else Mm), x=x, Y=Y, seed=0, **h)
+            hs.rng = np.random.default_rng(11 + b)
+            single, _ = hs.main_hmc_loop()
+            assert np.allclose(single, sd[:, b, :], rtol=1e-9, atol=1e-11), (kind, b)
+    # back to the identity: the mass matrix is per-run state of the context
+    ident = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-5, num_steps_in_leap=L, seed=11)
+    si, _ = ident.run(2)
+    ref = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-5, num_steps_in_leap=L, seed=11, device_resident=False)
+    sr, _ = ref.run(2)
+    assert np.array_equal(si, sr)
 
 
 @pytest.mark.gpu
