@@ -102,8 +102,8 @@ class HipBackend:
     def chains(self, d, allp, hv, groups):
         return HipChains(self.local_rank, d, allp, hv, groups)
 
-    def subjects(self, subs, pars, hv):
-        return HipSubjects(self.local_rank, subs, pars, hv)
+    def subjects(self, subs, pars, hv, chains_per_subject=1):
+        return HipSubjects(self.local_rank, subs, pars, hv, chains_per_subject)
 
 
 class HipChains:
@@ -159,13 +159,13 @@ class HipChains:
 class HipSubjects:
     """The rank's subjects as ONE multi-subject batch (own x, Y and prior factors per batch element)."""
 
-    def __init__(self, device, subs, pars, hv):
+    def __init__(self, device, subs, pars, hv, chains_per_subject=1):
         from nonstationary_multivariate_gaussian_process_amd import _lib
         self.hv = hv
         self.ctx = _lib.Context(device)
         self.ctx.set_data(subs[0]["x"], subs[0]["Y"])
-        self.ctx.svc_batch_alloc(len(subs))
-        self.ctx.svc_batch_set_subjects(np.stack([d["x"] for d in subs]), np.stack([d["Y"] for d in subs]))
+        self.ctx.svc_batch_alloc(len(subs) * chains_per_subject)
+        self.ctx.svc_batch_set_subjects(np.stack([d["x"] for d in subs]), np.stack([d["Y"] for d in subs]), chains_per_subject)
         self.ctx.svc_batch_set_pars(pars)
         self.grads = None
 
@@ -452,8 +452,9 @@ def run_subjects(a, rank, world, be):
     hyper = sim.HYPER_SVC_MPISIM
     hv = np.array([hyper[k] for k in SVC_KEYS], dtype=np.float64)
     subs = [sim.simulate_nonseparable(N, M, seed=s_id) for s_id in mine]       # subject s uses seed s (sim.py:361-363)
-    pars = np.stack([sim.perturb(d["pars_true"], 0.05, 0.7) for d in subs])
-    ev = be.subjects(subs, pars, hv)
+    K = max(1, a.chains_per_subject)            # chains per subject in the rank's batch (subject-major)
+    pars = np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * k) for d in subs for k in range(K)])
+    ev = be.subjects(subs, pars, hv, K) if K > 1 else be.subjects(subs, pars, hv)
     want_grad = bool(a.grad)
     prof = getattr(ev, "ctx", None)
     if prof is not None:
@@ -467,23 +468,26 @@ def run_subjects(a, rank, world, be):
     stage = prof.profile_read() if prof is not None else {}
     if prof is not None:
         prof.profile_enable(False)
-    stats, table = chains.reduce_rows(unit_rows(mine, a.steps, outs, status), n_subj, world, device=be.device)
+    unit_ids = [s_id * K + k for s_id in mine for k in range(K)]
+    stats, table = chains.reduce_rows(unit_rows(unit_ids, a.steps, outs, status), n_subj * K, world, device=be.device)
     rec = None
     if rank == 0:
         n = N * M
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items() if v[1] > 0}
         chol_s = stage_ms.get("chol", 0.0) * 1e-3
-        fact_tf = (len(mine) * (2.0 if want_grad else 1.0) * float(n) ** 3 / 3.0) / chol_s / 1e12 if chol_s > 0 else 0.0
-        total = a.steps * n_subj
-        traffic, traffic_note = measured_traffic(N, M, len(mine), want_grad, "subjects")
+        fact_tf = (len(mine) * K * (2.0 if want_grad else 1.0) * float(n) ** 3 / 3.0) / chol_s / 1e12 if chol_s > 0 else 0.0
+        total = a.steps * n_subj * K
+        traffic, traffic_note = measured_traffic(N, M, len(mine) * K, want_grad, "subjects")
         rec = {
             "metric": "log-posterior evals/sec (%d subjects, N=%d, D=%d nonseparable GP)" % (n_subj, N, M),
             "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d independent subjects (%d per GPU, one multi-subject batch per GPU), "
+            "config": {"workload": "%d independent subjects (%d per GPU, one multi-subject batch per GPU%s), "
                                    "nlogpos_obj_SVC %s, D=%d, N=%d" % (n_subj, a.subjects_per_gpu,
+                                                                       ", %d chains per subject" % K if K > 1 else "",
                                                                        "value+gradient" if want_grad else "value", M, N),
+                       "chains_per_subject": K,
                        "subjects_total": n_subj, "subjects_ok": int(stats[0]), "subjects_failed": int(stats[1]),
                        "sum_neglog": float(stats[3]), "subject_table_rows": int(table.shape[0]), "stage_ms": stage_ms},
             "roofline": {"kernel": "blocked FP64 Cholesky stage of rank 0's multi-subject batch (k_syrk_lower + panel "
@@ -519,6 +523,9 @@ def parse_args(argv=None):
                     help="chain: B chains of one N=2048 subject per GPU (headline); subjects: BASELINE config 4, "
                          "independent subjects of size --N sharded round-robin over the GPUs (8 per GPU), one batch each")
     ap.add_argument("--subjects-per-gpu", type=int, default=8)
+    ap.add_argument("--chains-per-subject", type=int, default=1,
+                    help="workload subjects: chains per subject in the rank's batch (they share the subject's data and prior "
+                         "factors on the device); a step then evaluates subjects x chains parameter vectors")
     ap.add_argument("--chains", type=int, default=128,
                     help="independent MCMC chains of the subject evaluated per step through the batched entry "
                          "(nmgp_svc_batch_*): one launch sequence covers all chains")

@@ -97,6 +97,10 @@ int nmgp_svc_batch_set_pars(nmgp_ctx* ctx, const double* pars);
  * its own GP-prior factors -- BASELINE config 4, the reference's one-process-per-subject pattern in one launch
  * sequence.  Without this call all batch elements are chains of the subject given to nmgp_set_data. */
 int nmgp_svc_batch_set_subjects(nmgp_ctx* ctx, const double* x, const double* Y);
+/* Several chains per subject: x [S, N], Y [S, N, M] with S = batch / chains_per_subject; batch element b = s * chains_per_subject + k
+ * is chain k of subject s (its parameter vector: row b of nmgp_svc_batch_set_pars).  The chains of a subject share its inputs and its
+ * GP-prior factors.  (The reference runs one process per subject and chain: Nonseparable_model_mpisim.py:305-348.) */
+int nmgp_svc_batch_set_subjects_chains(nmgp_ctx* ctx, const double* x, const double* Y, int chains_per_subject);
 double* nmgp_svc_batch_pars_dev(nmgp_ctx* ctx);
 int nmgp_svc_batch_eval(nmgp_ctx* ctx, const double hyper[8], int prior, int want_grad);
 int nmgp_svc_batch_fetch(nmgp_ctx* ctx, double* out, int* status);

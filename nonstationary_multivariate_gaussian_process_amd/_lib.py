@@ -47,6 +47,7 @@ SIGNATURES = {
     "nmgp_svc_batch_fetch_grad": (I, [V, P]),
     "nmgp_svc_batch_grad_dev": (V, [V]),
     "nmgp_svc_batch_fetch": (I, [V, P, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_set_subjects_chains": (I, [V, P, P, I]),
     "nmgp_svc_batch_traj_begin": (I, [V]),
     "nmgp_svc_batch_traj_set_mass": (I, [V, I, P]),
     "nmgp_svc_batch_traj": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
@@ -228,13 +229,18 @@ class Context:
         self.check(self.lib.nmgp_svc_batch_set_pars(self.h, ptr(pars)))
         self.sync()
 
-    def svc_batch_set_subjects(self, xs, Ys):
-        """Every batch element becomes its own subject: xs [B, N], Ys [B, N, M] (same N, M as set_data)."""
+    def svc_batch_set_subjects(self, xs, Ys, chains_per_subject=1):
+        """The batch holds S = B / chains_per_subject subjects: xs [S, N], Ys [S, N, M] (same N, M as set_data); batch element
+        b = s * chains_per_subject + k is chain k of subject s.  With the default of 1 every batch element is its own subject."""
         xs, Ys = as_f64(xs), as_f64(Ys)
-        if xs.shape != (self.B, self.N) or Ys.shape != (self.B, self.N, self.M):
-            raise NmgpError("subjects must be xs [B=%d, N=%d], Ys [B, N, M=%d]; got %s, %s"
-                            % (self.B, self.N, self.M, xs.shape, Ys.shape))
-        self.check(self.lib.nmgp_svc_batch_set_subjects(self.h, ptr(xs), ptr(Ys)))
+        k = int(chains_per_subject)
+        if k < 1 or self.B % k:
+            raise NmgpError("the batch size %d is not a multiple of chains_per_subject = %d" % (self.B, k))
+        S = self.B // k
+        if xs.shape != (S, self.N) or Ys.shape != (S, self.N, self.M):
+            raise NmgpError("subjects must be xs [S=%d, N=%d], Ys [S, N, M=%d]; got %s, %s"
+                            % (S, self.N, self.M, xs.shape, Ys.shape))
+        self.check(self.lib.nmgp_svc_batch_set_subjects_chains(self.h, ptr(xs), ptr(Ys), k))
 
     def svc_batch_eval(self, hyper, prior=True, want_grad=False):
         hyper = as_f64(hyper)

@@ -654,6 +654,7 @@ static void free_batch(nmgp_ctx* c) {
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
                        &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel};
     c->b_mass_kind = 0;
+    c->b_cps = 1;
     if (c->b_alive) hipFree(c->b_alive);
     c->b_alive = nullptr;
     c->b_adam_t = -1;
@@ -719,14 +720,24 @@ extern "C" double* nmgp_svc_batch_pars_dev(nmgp_ctx* c) { return c ? c->b_pars :
 // Nonseparable_model_mpisim.py:305-306): batch element b gets its own inputs x[b], Y[b] and its own GP-prior factors.
 // x: [B, N], Y: [B, N, M] row-major.  N and M are those of nmgp_set_data (whose subject is then ignored by the batch).
 extern "C" int nmgp_svc_batch_set_subjects(nmgp_ctx* c, const double* x, const double* Y) {
+    return nmgp_svc_batch_set_subjects_chains(c, x, Y, 1);
+}
+
+// The same with SEVERAL chains per subject: x [S, N], Y [S, N, M] for S = batch / chains_per_subject subjects; batch element
+// b = s * chains_per_subject + k is chain k of subject s.  The chains of a subject share its inputs and its GP-prior factors (one
+// pair per SUBJECT, not per chain).  8 subjects x 8 chains on one GPU is config 4's per-GPU subject count at the batch size
+// where the factorisation is throughput-bound, and several chains per subject is what an R-hat needs anyway.
+extern "C" int nmgp_svc_batch_set_subjects_chains(nmgp_ctx* c, const double* x, const double* Y, int chains_per_subject) {
     if (!c) return NMGP_E_NULL;
     if (!x || !Y) return nmgp_fail(c, NMGP_E_NULL, "x/Y must not be NULL");
     if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    if (chains_per_subject < 1 || c->batch % chains_per_subject != 0)
+        return nmgp_fail(c, NMGP_E_SHAPE, "the batch size %d is not a multiple of chains_per_subject = %d", c->batch, chains_per_subject);
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t B = c->batch, N = c->N, M = c->M, n = c->n;
+    const size_t B = (size_t)c->batch / chains_per_subject, N = c->N, M = c->M, n = c->n;      // B = subjects
     hipStream_t s = c->stream;
-    if (!c->b_x) NMGP_TRY(nmgp_dev_alloc(c, &c->b_x, B * N));
-    if (!c->b_y) NMGP_TRY(nmgp_dev_alloc(c, &c->b_y, B * n));
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_x, B * N));      // (re-allocated: the number of subjects may differ from the last call)
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_y, B * n));
     double* tmp;
     NMGP_TRY(nmgp_scratch_get(c, 2, B * n, &tmp));
     HIP_TRY(c, hipMemcpyAsync(c->b_x, x, B * N * sizeof(double), hipMemcpyHostToDevice, s));
@@ -739,6 +750,7 @@ extern "C" int nmgp_svc_batch_set_subjects(nmgp_ctx* c, const double* x, const d
     }
     c->b_priors.clear();
     c->b_multi = true;
+    c->b_cps = chains_per_subject;
     return 0;
 }
 
@@ -752,7 +764,7 @@ static int get_batch_prior(nmgp_ctx* c, double alpha, double beta, PriorFactor**
     PriorFactor pf;
     pf.alpha = alpha;
     pf.beta = beta;
-    const size_t N = c->N, B = c->batch;
+    const size_t N = c->N, B = (size_t)c->batch / c->b_cps;      // one factor per SUBJECT
     pf.ld = (int)(((N + 15) / 16) * 16);
     NMGP_TRY(nmgp_dev_alloc(c, &pf.L, B * (size_t)pf.ld * N));
     if (nmgp_dev_alloc(c, &pf.logdet, B) != 0) {
@@ -819,7 +831,8 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_L = hyper[3], al_L = hyper[4], be_L = hyper[5];
     const double a = hyper[6], b = hyper[7];
     hipStream_t s = c->stream;
-    const bool multi = c->b_multi;                  // every batch element is its own subject
+    const bool multi = c->b_multi;                  // the batch holds several subjects (b_cps consecutive chains each)
+    const int cps = multi ? c->b_cps : 1;
     const double* xs = multi ? c->b_x : c->d_x;
     const int xstride = multi ? N : 0;
     PriorFactor *pl = nullptr, *pL = nullptr;
@@ -838,13 +851,13 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     {
         StageScope sp(c, NMGP_STAGE_COV);
         svc_prep(s, c->b_pars, N, M, c->b_ell, c->b_Lv, B);
-        int r = svc_cov_build(s, xs, c->b_ell, c->b_Lv, c->b_pars + (P - 1), S, ld, N, M, false, B, bs, xstride);
+        int r = svc_cov_build(s, xs, c->b_ell, c->b_Lv, c->b_pars + (P - 1), S, ld, N, M, false, B, bs, xstride, cps);
         if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
     }
     {
         StageScope sp(c, NMGP_STAGE_CHOL);
         // one subject: every chain shares y (vstride 0); multi-subject: y of batch element b
-        set_row(s, S, ld, n, multi ? c->b_y : c->d_y, n, B, bs, multi ? n : 0);
+        set_row(s, S, ld, n, multi ? c->b_y : c->d_y, n, B, bs, multi ? n : 0, cps);
         if (want_grad) identity_rows(s, S, ld, n + 1, n, xpad, B, bs);
         potrf_lower(s, c->stream2, nmgp_chol_events(c, n), S, ld, n, want_grad ? 1 + xpad : 1, want_grad ? n : 0, c->chol_nb1,
                     c->b_info, B, bs, 1, nmgp_syrk_hook(c));
@@ -877,7 +890,27 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
                 // one streaming pass per right-hand side over its factor (k_prior_trsv; per-subject factors in a multi-subject
                 // batch, the subject's shared factors otherwise: stride 0)
                 prior_trsv(ps.sp, pass == 1, pl->L, pl->ld, multi ? (long long)pl->ld * N : 0, pL->L, pL->ld,
-                           multi ? (long long)pL->ld * N : 0, R, N, 1 + T, (int)B);
+                           multi ? (long long)pL->ld * N : 0, R, N, 1 + T, (int)B, cps);
+            } else if (multi && cps > 1) {
+                // several chains per subject through the library: the chains of a subject are consecutive, so their (1 + T) cps
+                // columns form one right-hand-side block per subject
+                const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;
+                const rocblas_stride sB = (rocblas_stride)(1 + T) * N;
+                const int S_ = B / cps;
+                for (int sj = 0; sj < S_; ++sj) {
+                    double* Rs = R + (size_t)sj * cps * sB;
+                    if (same) {
+                        BLAS_TRY(c, rocblas_dtrsm(ps.hb, rocblas_side_left, rocblas_fill_lower, op, rocblas_diagonal_non_unit, N,
+                                                  cps * (1 + T), &one, pl->L + (size_t)sj * sA_l, pl->ld, Rs, N));
+                    } else {
+                        BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
+                                                                  rocblas_diagonal_non_unit, N, 1, &one, pl->L + (size_t)sj * sA_l,
+                                                                  pl->ld, 0, Rs, N, sB, cps));
+                        BLAS_TRY(c, rocblas_dtrsm_strided_batched(ps.hb, rocblas_side_left, rocblas_fill_lower, op,
+                                                                  rocblas_diagonal_non_unit, N, T, &one, pL->L + (size_t)sj * sA_L,
+                                                                  pL->ld, 0, Rs + N, N, sB, cps));
+                    }
+                }
             } else if (multi) {
                 // per-subject factors: strided-batched solves (columns of chain b start at b (1+T) N)
                 const rocblas_stride sA_l = (rocblas_stride)pl->ld * N, sA_L = (rocblas_stride)pL->ld * N;
@@ -918,7 +951,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         StageScope sp(c, NMGP_STAGE_REDUCE);
         const double ig_const = a * std::log(b) - std::lgamma(a);
         svc_finalize(s, c->b_scal, c->b_scal + 1, c->b_q, pl->logdet, pL->logdet, c->b_pars, P, N, T, a, b, ig_const,
-                     prior, c->b_scal + 8, B, 16, multi ? 1 : 0);
+                     prior, c->b_scal + 8, B, 16, multi ? 1 : 0, cps);
     }
     if (want_grad) {
         {
@@ -928,7 +961,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
         {
             StageScope sp(c, NMGP_STAGE_ADJOINT);
             trace_terms(s, c->b_alpha, c->b_Sinv, n, n, c->b_tr, -1.0, B);
-            int r = svc_adjoint(s, xs, c->b_ell, c->b_Lv, c->b_alpha, c->b_Sinv, n, N, M, c->b_part, -1.0, B, xstride);
+            int r = svc_adjoint(s, xs, c->b_ell, c->b_Lv, c->b_alpha, c->b_Sinv, n, N, M, c->b_part, -1.0, B, xstride, cps);
             if (r) return nmgp_fail(c, r, "unsupported number of outputs M=%d", M);
             svc_grad_final(s, c->b_part, (N + 63) / 64, N, M, c->b_Lv, c->b_R2, N, c->b_pars, c->b_tr, a, b, prior,
                            c->b_grad, B);

@@ -1827,14 +1827,15 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
 
 // A[row, j] = v[j]  (the extra row carrying the right-hand side)
 // vstride = 0 broadcasts one vector to every matrix of the batch (all chains of a subject share y)
+// (cps: consecutive groups of cps matrices share one vector -- the chains of a subject in a multi-subject batch)
 __global__ void k_set_row(double* __restrict__ A, int lda, int row, const double* __restrict__ v, int n,
-                          long long bstride, long long vstride) {
+                          long long bstride, long long vstride, int cps) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) A[(size_t)blockIdx.y * bstride + (size_t)j * lda + row] = v[(size_t)blockIdx.y * vstride + j];
+    if (j < n) A[(size_t)blockIdx.y * bstride + (size_t)j * lda + row] = v[(size_t)(blockIdx.y / cps) * vstride + j];
 }
 void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n, int batch, long long bstride,
-             long long vstride) {
-    NMGP_LAUNCH(k_set_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride);
+             long long vstride, int cps) {
+    NMGP_LAUNCH(k_set_row, dim3(cdiv_c(n, 256), batch), dim3(256), 0, s, A, lda, row, v, n, bstride, vstride, cps < 1 ? 1 : cps);
 }
 __global__ void k_get_row(const double* __restrict__ A, int lda, int row, double* __restrict__ v, int n,
                           long long bstride, long long vstride) {

@@ -139,6 +139,7 @@ struct nmgp_ctx {
     double* b_x = nullptr;      // [B, N]
     double* b_y = nullptr;      // [B, n] output-major
     std::vector<PriorFactor> b_priors;   // L: [B] x (ld x N), logdet: [B]
+    int b_cps = 1;              // chains per subject of a multi-subject batch: batch element z belongs to subject z / b_cps
     int b_mass_kind = 0;        // mass matrix of the device-resident trajectories: 0 identity, 1 diagonal, 2 dense (b_minv = M^-1)
     double* b_minv = nullptr;   // [P] or [P, P]
     double* b_vel = nullptr;    // [B, P] velocities M^-1 p (dense mass matrix)
@@ -256,7 +257,7 @@ namespace nmgpk {
 void svc_prep(hipStream_t s, const double* pars, int N, int M, double* ell, double* Lv, int batch = 1);
 // kernel #1: fused nonseparable covariance (lower triangle, column-major, output-major indices)
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                  double* S, int ld, int N, int M, bool full, int batch = 1, long long sstride = 0, int xstride = 0);
+                  double* S, int ld, int N, int M, bool full, int batch = 1, long long sstride = 0, int xstride = 0, int cps = 1);
 // symmetric N x N builds (lower triangle unless full)
 void rbf_cov_sym(hipStream_t s, const double* x, int N, double alpha, double beta, double* out, int ld, bool full,
                  int batch = 1);
@@ -275,7 +276,7 @@ void chol_logdet_quad(hipStream_t s, const double* L, int ld, int n, const doubl
 void col_sumsq(hipStream_t s, const double* R, int ld, int rows, int cols, double* out);
 // op(L) x = r for the columns r of R ([N] each, nrhs per batch element); column 0 uses L0, the others L1; N <= 3500 (LDS)
 void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
-                double* R, int N, int nrhs, int batch);
+                double* R, int N, int nrhs, int batch, int cps = 1);
 void diag_logsum2(hipStream_t s, const double* L, int ld, int n, double* out);
 void fill_lower_to_full(hipStream_t s, double* A, int ld, int n, int batch = 1);
 void transpose_y(hipStream_t s, const double* Y, int N, int M, double* y);
@@ -292,7 +293,7 @@ void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const do
                  const int* accept, long long P, int B);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
-                int xstride = 0);
+                int xstride = 0, int cps = 1);
 // out = W z, W upper triangular (n x n, column-major with leading dimension ld; the zeros left of the diagonal are stored);
 // part: n * ceil(n / 256) doubles of scratch per matrix
 void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double* z, double* out, double* part, int batch = 1,
@@ -304,7 +305,7 @@ void svc_grad_final(hipStream_t s, const double* part, int NJ, int N, int M, con
                     int batch = 1);
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5, int batch = 1, int sstride = 0, int hstride = 0);
+                  double ig_const, int prior, double* out5, int batch = 1, int sstride = 0, int hstride = 0, int cps = 1);
 void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int batch = 1);
 // ---- nmgp_kernels_eig.hip ----
 int kron_mv(hipStream_t s, const double* K, int n1, int n2, const double* y, const double* B, int m1, int m2,
@@ -355,7 +356,7 @@ void potf2_64(hipStream_t s, double* A, int lda, int nb, int* info, int goff, in
 void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda, int rows, int batch,
              long long bstride);
 void set_row(hipStream_t s, double* A, int lda, int row, const double* v, int n, int batch, long long bstride,
-             long long vstride);
+             long long vstride, int cps = 1);
 void get_row(hipStream_t s, const double* A, int lda, int row, double* v, int n, int batch, long long bstride,
              long long vstride);
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,

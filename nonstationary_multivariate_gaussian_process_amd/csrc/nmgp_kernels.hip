@@ -70,15 +70,16 @@ template <int M, bool FULL>
 __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, const double* __restrict__ ell,
                                                   const double* __restrict__ Lv, const double* __restrict__ tse,
                                                   double* __restrict__ S, int ld, int N, long long sstride,
-                                                  int xstride) {
+                                                  int xstride, int cps) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T];
     const int I = blockIdx.x, J = blockIdx.y;
     if (!FULL && M == 1 && I < J) return;
     // blockIdx.z = chain of the batch: one covariance buffer per chain; xstride = 0 when all chains belong to one
-    // subject (shared x), N when every batch element is its own subject
-    x += (size_t)blockIdx.z * xstride;
+    // subject (shared x), N when the batch holds several subjects: batch element z belongs to subject z / cps (cps chains per
+    // subject, consecutive)
+    x += (size_t)(blockIdx.z / cps) * xstride;
     ell += (size_t)blockIdx.z * N;
     Lv += (size_t)blockIdx.z * N * T;
     tse += (size_t)blockIdx.z * ((size_t)N * (1 + T) + 1);
@@ -136,25 +137,26 @@ __global__ __launch_bounds__(256) void k_svc_cov(const double* __restrict__ x, c
 
 template <int M>
 static void launch_svc_cov(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse,
-                           double* S, int ld, int N, bool full, int batch, long long sstride, int xstride) {
+                           double* S, int ld, int N, bool full, int batch, long long sstride, int xstride, int cps) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);
     if (full)
-        NMGP_LAUNCH((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
+        NMGP_LAUNCH((k_svc_cov<M, true>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride, cps);
     else
-        NMGP_LAUNCH((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride);
+        NMGP_LAUNCH((k_svc_cov<M, false>), grid, dim3(256), 0, s, x, ell, Lv, tse, S, ld, N, sstride, xstride, cps);
 }
 
 int svc_cov_build(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* tse, double* S,
-                  int ld, int N, int M, bool full, int batch, long long sstride, int xstride) {
+                  int ld, int N, int M, bool full, int batch, long long sstride, int xstride, int cps) {
+    if (cps < 1) cps = 1;
     switch (M) {
-        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
-        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride); break;
+        case 1: launch_svc_cov<1>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 2: launch_svc_cov<2>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 3: launch_svc_cov<3>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 4: launch_svc_cov<4>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 5: launch_svc_cov<5>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 6: launch_svc_cov<6>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 7: launch_svc_cov<7>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
+        case 8: launch_svc_cov<8>(s, x, ell, Lv, tse, S, ld, N, full, batch, sstride, xstride, cps); break;
         default: return NMGP_E_UNSUPPORTED;
     }
     return 0;
@@ -632,11 +634,11 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
                                                       const double* __restrict__ Lv,
                                                       const double* __restrict__ alpha,
                                                       const double* __restrict__ Sinv, int ld, int N,
-                                                      double* __restrict__ part, double ssign, int xstride) {
+                                                      double* __restrict__ part, double ssign, int xstride, int cps) {
     constexpr int T = M * (M + 1) / 2;
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], sL[TJ * T], sa[TJ * M];
-    x += (size_t)blockIdx.z * xstride;
+    x += (size_t)(blockIdx.z / cps) * xstride;          // (subject of batch element z: see k_svc_cov)
     __shared__ double red[2][4][64];
     const int I = blockIdx.x, J = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -723,10 +725,11 @@ __global__ __launch_bounds__(256) void k_svc_adjoint(const double* __restrict__ 
 
 // ssign = +1 when Sinv holds Sigma^-1 (rocSOLVER potri), -1 when it holds -Sigma^-1 (C -= X X^T of the custom path)
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
-                const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch, int xstride) {
+                const double* Sinv, int ld, int N, int M, double* part, double ssign, int batch, int xstride, int cps) {
     dim3 grid(cdiv(N, 64), cdiv(N, 64), batch);      // batched: Sinv matrices are ld x (N M) apart (ld == N M there)
+    if (cps < 1) cps = 1;
 #define NMGP_ADJ(MM) \
-    NMGP_LAUNCH((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign, xstride)
+    NMGP_LAUNCH((k_svc_adjoint<MM>), grid, dim3(256), 0, s, x, ell, Lv, alpha, Sinv, ld, N, part, ssign, xstride, cps)
     switch (M) {
         case 1: NMGP_ADJ(1); break;
         case 2: NMGP_ADJ(2); break;
@@ -830,10 +833,10 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
                                const double* __restrict__ q, const double* __restrict__ hl_l,
                                const double* __restrict__ hl_L, const double* __restrict__ pars, long long P, int N,
                                int T, double a, double b, double ig_const, int prior, double* __restrict__ out5,
-                               int sstride, int hstride) {
+                               int sstride, int hstride, int cps) {
     if (threadIdx.x != 0) return;
-    hl_l += (size_t)blockIdx.x * hstride;      // per-subject prior factors in a multi-subject batch
-    hl_L += (size_t)blockIdx.x * hstride;
+    hl_l += (size_t)(blockIdx.x / cps) * hstride;      // per-subject prior factors in a multi-subject batch
+    hl_L += (size_t)(blockIdx.x / cps) * hstride;
     // blockIdx.x = chain: scalar blocks are sstride apart, prior terms 1 + T apart, parameter vectors P apart
     logdet += (size_t)blockIdx.x * sstride;
     quad += (size_t)blockIdx.x * sstride;
@@ -865,9 +868,9 @@ __global__ void k_svc_finalize(const double* __restrict__ logdet, const double* 
 
 void svc_finalize(hipStream_t s, const double* logdet, const double* quad, const double* q, const double* hl_l,
                   const double* hl_L, const double* pars, long long P, int N, int T, double a, double b,
-                  double ig_const, int prior, double* out5, int batch, int sstride, int hstride) {
+                  double ig_const, int prior, double* out5, int batch, int sstride, int hstride, int cps) {
     NMGP_LAUNCH(k_svc_finalize, dim3(batch), dim3(64), 0, s, logdet, quad, q, hl_l, hl_L, pars, P, N, T, a, b,
-                       ig_const, prior, out5, sstride, hstride);
+                       ig_const, prior, out5, sstride, hstride, cps < 1 ? 1 : cps);
 }
 
 // half log-determinant of a Cholesky factor: sum log L_rr
@@ -899,9 +902,9 @@ void half_logdet(hipStream_t s, const double* L, int ld, int n, double* out, int
 template <bool TRANS>
 __global__ __launch_bounds__(1024) void k_prior_trsv(const double* __restrict__ L0, int ld0, long long s0,
                                                       const double* __restrict__ L1, int ld1, long long s1,
-                                                      double* __restrict__ R, int N, int nrhs) {
+                                                      double* __restrict__ R, int N, int nrhs, int cps) {
     const int j = blockIdx.x, b = blockIdx.y;
-    const double* L = (j == 0 ? L0 + (size_t)b * s0 : L1 + (size_t)b * s1);
+    const double* L = (j == 0 ? L0 + (size_t)(b / cps) * s0 : L1 + (size_t)(b / cps) * s1);      // factors of subject b / cps
     const int ld = (j == 0 ? ld0 : ld1);
     double* r = R + ((size_t)b * nrhs + j) * N;
     extern __shared__ double sh[];
@@ -1021,12 +1024,13 @@ __global__ __launch_bounds__(1024) void k_prior_trsv(const double* __restrict__ 
 }
 
 void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
-                double* R, int N, int nrhs, int batch) {
+                double* R, int N, int nrhs, int batch, int cps) {
     const size_t lds = ((size_t)N + 2 + 64 * 65 + 64) * sizeof(double);
+    if (cps < 1) cps = 1;
     if (trans)
-        NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs, cps);
     else
-        NMGP_LAUNCH(k_prior_trsv<false>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs);
+        NMGP_LAUNCH(k_prior_trsv<false>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs, cps);
 }
 
 }  // namespace nmgpk

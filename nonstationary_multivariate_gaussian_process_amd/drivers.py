@@ -434,11 +434,15 @@ class BatchedHMC(LockStepHMC):
     Nonseparable model only (the batched entry point of the C ABI).  ``M`` / ``Minv``: constant mass matrix shared by the
     chains (None: identity; [P]: diagonal; [P, P]: dense, as the reference's production sampler passes it,
     Nonseparable_model_mpiKAISER.py:267-270,398-411) -- resident on the device, the drift of every leapfrog step is one GEMM.
-    ``x`` [N], ``Y`` [N, M]: B chains of one subject; ``x`` [B, N], ``Y`` [B, N, M]: one chain per subject.
+    ``x`` [N], ``Y`` [N, M]: B chains of one subject; ``x`` [S, N], ``Y`` [S, N, M]: S subjects with ``chains_per_subject``
+    chains each (default 1: config 4's unit, one chain per subject), ``init_positions`` [S * chains_per_subject, P] subject-major
+    (row s * chains_per_subject + k = chain k of subject s).  The chains of a subject share its data and prior factors on the
+    device; 8 subjects x 8 chains is config 4's per-GPU subject count at a batch size where the factorisation is
+    throughput-bound, and what a between-chain diagnostic (R-hat) needs.
     """
 
     def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
-                 device_resident=True, M=None, Minv=None):
+                 device_resident=True, M=None, Minv=None, chains_per_subject=1):
         from . import _lib
         super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
         self.device_resident = bool(device_resident)
@@ -448,11 +452,12 @@ class BatchedHMC(LockStepHMC):
         x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         if x.ndim == 2:
             # one chain per SUBJECT (BASELINE config 4's unit: x [B, N], Y [B, N, M], every subject with its own prior factors)
-            if x.shape[0] != self.B or Y.shape[0] != self.B:
-                raise ValueError("x [B, N] and Y [B, N, M] must have one subject per chain")
+            k = int(chains_per_subject)
+            if k < 1 or x.shape[0] * k != self.B or Y.shape[0] * k != self.B:
+                raise ValueError("x [S, N] and Y [S, N, M] must hold B / chains_per_subject = %d / %d subjects" % (self.B, k))
             self.ctx.set_data(x[0], Y[0])
             self.ctx.svc_batch_alloc(self.B)
-            self.ctx.svc_batch_set_subjects(x, Y)
+            self.ctx.svc_batch_set_subjects(x, Y, k)
         else:
             self.ctx.set_data(x, Y)
             self.ctx.svc_batch_alloc(self.B)

@@ -303,6 +303,50 @@ def test_one_hmc_chain_per_subject_equals_the_subjects_sampled_one_at_a_time():
 
 
 @pytest.mark.gpu
+def test_several_hmc_chains_per_subject_share_the_subject_on_the_device():
+    """BatchedHMC(xs [S, N], Ys, chains_per_subject=k): S subjects x k chains in ONE batch, the chains of a subject sharing its
+    inputs and GP-prior factors (nmgp_svc_batch_set_subjects_chains).  Chain (s, k) must equal that chain run alone on its subject
+    with the same random stream; value-only and value+gradient evaluations of the mixed batch equal single evaluations."""
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    from nonstationary_multivariate_gaussian_process_amd.drivers import BatchedHMC
+    S_, K, N, M, samples = 3, 2, 48, 3, 3
+    subs = [sim.simulate_nonseparable(N, M, seed=30 + s) for s in range(S_)]
+    xs, Ys = np.stack([d["x"] for d in subs]), np.stack([d["Y"] for d in subs])
+    init = np.stack([sim.perturb(subs[s]["pars_true"], 0.02, 0.3 * s + 0.7 * k) for s in range(S_) for k in range(K)])
+    h = sim.HYPER_SVC_MPISIM
+    hv = [h[k] for k in SVC_KEYS]
+    # one evaluation of the mixed batch against single-subject evaluations
+    c = _lib.Context(0)
+    try:
+        c.set_data(xs[0], Ys[0])
+        c.svc_batch_alloc(S_ * K)
+        c.svc_batch_set_subjects(xs, Ys, K)
+        c.svc_batch_set_pars(init)
+        c.svc_batch_eval(hv, True, True)
+        out, st = c.svc_batch_fetch()
+        grads = c.svc_batch_fetch_grad()
+        assert np.all(st == 0)
+        for s in range(S_):
+            c.set_data(xs[s], Ys[s])
+            for k in range(K):
+                o1, g1 = c.logpos_svc(init[s * K + k], hv, prior=True, want_grad=True)
+                # (the batch solves the prior systems by substitution, the single evaluation through the library: kappa * eps apart)
+                assert np.allclose(out[s * K + k], o1, rtol=1e-10, atol=0)
+                assert np.linalg.norm(grads[s * K + k] - g1) < 1e-7 * np.linalg.norm(g1)
+    finally:
+        c.close()
+    allb = BatchedHMC(xs, Ys, h, init, step_size=5e-5, num_steps_in_leap=6, seed=5, chains_per_subject=K)
+    smp, info = allb.run(samples)
+    assert np.all(info["accept_rate"] > 0)
+    for s in range(S_):
+        for k in range(K):
+            b = s * K + k
+            one = BatchedHMC(subs[s]["x"], subs[s]["Y"], h, init[b:b + 1], step_size=5e-5, num_steps_in_leap=6, seed=5 + b)
+            sb, _ = one.run(samples)
+            assert np.allclose(sb[:, 0], smp[:, b], rtol=1e-9, atol=1e-11), (s, k)
+
+
+@pytest.mark.gpu
 def test_config1_stationary_200_mcmc_iterations_follow_the_cpu_oracle():
     """BASELINE config 1 (stationary GP, D = 2, N = 128, 200 MCMC iterations -- the reference's CPU-runnable case): the same
     HMC loop, random stream and start, once with the MI355X potential (``logpos.nlogpos_obj_S`` through the mirror) and once with
