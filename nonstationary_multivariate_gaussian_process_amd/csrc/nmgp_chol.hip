@@ -1969,11 +1969,54 @@ static bool panel_takes_fused_steps(int n, int w, int lda, int batch) {
     return can_fuse && (g_panel_mode == 1 || (g_panel_mode == 0 && small));
 }
 
+// Fused steps under a recursive split.  A fused step re-reads and re-writes ALL remaining columns of its panel (the delayed
+// K = 64 update): 1792 column-block passes per 512-wide panel against 768 for recursive halving.  For one matrix that is free --
+// a step's ~190 workgroups fit the 256 CUs in one round and the step is latency-bound (~25 us) -- but with 8 subjects a step of
+// the first panel is 720 workgroups at one per CU (118 KB of LDS) = three rounds, 72 us, bound by that traffic.  So the panel is
+// halved recursively (one K = w/2 update per level, ordinary update kernel with the next diagonal block fused) until the
+// pieces are `base` wide, and only those run as fused steps: base = 128 keeps recursive halving's 768 passes with 11 launches
+// per 512 columns instead of 23.  NMGP_CHOL_FUSED_BASE=<128|256|512|...>; auto: fused_base_width() below.
+static void factor_panel_fused_split(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int base,
+                                     int* info, int batch, long long bs, int is) {
+    if (w <= base) {
+        factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+        return;
+    }
+    int h = ((w / 2 + 63) / 64) * 64;
+    if (h >= w) h = ((w - 1) / 64) * 64;
+    factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, h, base, info, batch, bs, is);
+    const int c1 = c0 + h;
+    const int below = active_rows(n, extra, xtri, c1) - c1;
+    if (below > 0) {
+        arm_fused_block(info, is, c1, w - h);
+        syrk_lower(s, A + (size_t)c0 * lda + c1, lda, A + (size_t)c1 * lda + c1, lda, below, w - h, h, batch, bs, -1, 0,
+                   xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
+        g_fuse_next.info = nullptr;
+    }
+    factor_panel_fused_split(s, A, lda, n, extra, xtri, c1, w - h, base, info, batch, bs, is);
+}
+
+static int fused_base_width(int n, int extra, int xtri, int c0, int w, int batch) {
+    static const int env_base = [] {
+        const char* e = std::getenv("NMGP_CHOL_FUSED_BASE");
+        return e ? (std::atoi(e) / 64) * 64 : 0;
+    }();
+    if (env_base >= 64) return env_base;
+    // measured (MI355X, profiles/r03_fused_base.txt; evals/s at base 512 / 256 / 128): one chain 301 / 286 / 271; 4 chains 537 / 526 /
+    // 504; 8 chains 609 / 606 / 587; 8 subjects x N=1024 2935 / 2925 / 2779, value+gradient 1275 / 1338 / 1301; 16 subjects 3603 /
+    // 3828 / 3745; separable N=4096 D=5 3.92 / 4.01 / 4.12 ms, value+gradient 9.32 / 9.23 / 9.54 ms.  The K = 256 update a split
+    // inserts costs what the steps save until a step is well over two rounds of workgroups: 256 from 16 matrices on, and for
+    // gradient evaluations (twice the rows) from 5 matrices on.
+    (void)n; (void)extra; (void)c0;
+    if (w > 256 && (batch >= 16 || (xtri > 0 && batch >= 5))) return 256;
+    return w;
+}
+
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
     const int rec_min_batch = 4;                 // smallest batch that takes the recursive panels
     if (panel_takes_fused_steps(n, w, lda, batch))
-        factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+        factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, w, fused_base_width(n, extra, xtri, c0, w, batch), info, batch, bs, is);
     else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(512, 4) void k_syrk_fast(const double* __restrict__
     const int l15 = lane & 15, l4 = lane >> 4;
     // global -> LDS staging: thread (rp = tid & 63, cg = tid >> 6) moves rows 2rp, 2rp+1 of k-columns cg and cg + 8
     const int rp = tid & 63, cg = tid >> 6;
-    const int offA = (cg * lda + row0 + 2 * rp) * 8, offB = (cg * lda + col0 + 2 * rp) * 8;
+    // V & 32: every tile streams the SAME two row panels (rows 0.. and 128..): the k-loop is unchanged but all panel loads hit the
+    // L2 -- the speed a perfect L2 reuse of the A panels would give (results are wrong on purpose)
+    const int offA = (cg * lda + ((V & 32) ? 0 : row0) + 2 * rp) * 8, offB = (cg * lda + ((V & 32) ? 128 : col0) + 2 * rp) * 8;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     const int gstep = BK * lda * 8, ghalf = 8 * lda * 8;
     int soff = 0;
@@ -436,6 +438,7 @@ int main(int argc, char** argv) {
     run("w8_nomask_nopre_sched", [&] { hipLaunchKernelGGL((k_syrk<4, 16, 35>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("w4_nomask_sched", [&] { hipLaunchKernelGGL((k_syrk<2, 16, 33>), gs, dim3(256), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast", [&] { hipLaunchKernelGGL((k_syrk_fast<0>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
+    run("fast_samepanel", [&] { hipLaunchKernelGGL((k_syrk_fast<32>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_midstore", [&] { hipLaunchKernelGGL((k_syrk_fast<2>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_midstore_sched", [&] { hipLaunchKernelGGL((k_syrk_fast<3>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_sched", [&] { hipLaunchKernelGGL((k_syrk_fast<1>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
