@@ -314,13 +314,15 @@ def run_chains(a, rank, world, be):
         g_rate = a.grad_steps * world * B / g_elapsed
         g_tf = g_rate * float(n) ** 3 / 1e12 / world
         gnorm = float(np.linalg.norm(ev.grads[0])) if ev.grads is not None else None
+        g_traffic, g_traffic_note = measured_traffic(N, M, B, True) if prof is not None else (None, "no HIP backend")
         grad_rec = {"what": "nlogpos_obj_SVC value + gradient of every chain per step (gradients copied to the host "
                             "every step), same %d chain(s) per GPU" % B,
                     "value": g_rate, "unit": "evals/s", "steps": a.grad_steps, "ms_per_step": 1e3 * g_elapsed / a.grad_steps,
                     "chains_ok": int(np.sum(g_status == 0)), "grad_norm_chain0": gnorm,
                     "roofline": {"what": "end to end: n^3 flop per value+gradient evaluation (SURVEY 8d W_fb) x evals/s "
                                          "per GPU", "bound": "mfma", "achieved": g_tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS},
+                                 "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS,
+                                 "traffic": g_traffic, "traffic_note": g_traffic_note},
                     "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in g_stage.items() if v[1] > 0}}
     # end-to-end MCMC rate: BatchedHMC (drivers.py) advances B chains in lock-step, 20 leapfrog steps per sample, step size 1e-4
     # (Nonseparable_model.py:228-231), every step one batched value+gradient launch sequence + the leapfrog kernels.  Like the

@@ -23,4 +23,17 @@ cp $O/batched128_pmc_syrk_classes.json profiles/${P}_batched128_pmc_syrk_classes
 cp $O/traffic.json profiles/traffic.json
 tail -1 $O/bench_default.json > profiles/${P}_default_bench.json
 [ -f gpurun_out/parity_${P}.json ] && cp gpurun_out/parity_${P}.json profiles/parity_${P}.json
+cp $O/batched128_timeline.txt profiles/${P}_batched128_timeline.txt 2>/dev/null || true
+# the value+gradient step (tools/profile_grad.sh)
+if [ -f $O/g128_kernel_stats.csv ]; then
+    for f in kernel_stats.csv last_eval.txt syrk_classes.txt timeline.txt pmc_FETCH_SIZE.csv pmc_WRITE_SIZE.csv pmc_traffic.json pmc_syrk_classes.json; do
+        cp $O/g128_$f profiles/${P}_g128_$f
+    done
+    tail -1 $O/g128.json > profiles/${P}_g128_bench_under_rocprof.json
+fi
+# config 4's per-GPU shape under the counters, prediction at the reference's grid
+for f in s8_pmc_FETCH_SIZE.csv s8_pmc_WRITE_SIZE.csv s8_pmc_traffic.json pred_kernel_stats.csv; do
+    [ -f $O/$f ] && cp $O/$f profiles/${P}_$f
+done
+[ -f $O/pred_bench.json ] && tail -1 $O/pred_bench.json > profiles/${P}_pred_bench.json
 echo collected

@@ -49,6 +49,19 @@ python3 tools/pmc_classes.py "$O/batched128_pmc_FETCH_SIZE.csv" "$O/batched128_p
 # the default line is measured with the fresh traffic pin in place (bench.py reports roofline.traffic only for the kernel source
 # the PMC passes ran on); the pin travels back through gpurun_out/
 mkdir -p profiles && cp "$O/batched128_pmc_traffic.json" "profiles/${2:-r02}_batched128_pmc_traffic.json"
-python3 tools/pin_traffic.py "profiles/${2:-r02}_batched128_pmc_traffic.json" && cp profiles/traffic.json "$O/traffic.json"
+python3 tools/pin_traffic.py "profiles/${2:-r02}_batched128_pmc_traffic.json"
+# config 4's per-GPU shape (8 subjects x N = 1024, value): the traffic of `bench.py --workload subjects`
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c -d "$O/raw_pmc8_$c" -o pmc --output-format csv -- python3 "$R/bench.py" $Q --workload subjects --N 1024 --steps 2 --warmup 1 \
+        > "$O/s8_pmc_$c.json" 2> "$O/s8_pmc_$c.err"
+    cp "$(find "$O/raw_pmc8_$c" -name '*counter_collection.csv' | head -1)" "$O/s8_pmc_$c.csv"
+    rm -rf "$O/raw_pmc8_$c"
+done
+cd "$R"
+python3 tools/pmc_summary.py "$O/s8_pmc_FETCH_SIZE.csv" "$O/s8_pmc_WRITE_SIZE.csv" "$O/s8_pmc_traffic.json" "8 subjects x N=1024, $1"
+cp "$O/s8_pmc_traffic.json" "profiles/${2:-r02}_s8_pmc_traffic.json"
+python3 tools/pin_traffic.py "profiles/${2:-r02}_s8_pmc_traffic.json" 1024 3 8 0 subjects
+cp profiles/traffic.json "$O/traffic.json"
 python3 bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
 tail -1 "$O/bench_default.json" | cut -c1-400
