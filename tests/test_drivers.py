@@ -237,6 +237,27 @@ def test_device_resident_trajectories_equal_the_host_lock_step_loop_bit_for_bit(
         rates.append(idv["accept_rate"][[0, 1, 2, 4]])
     rates = np.concatenate(rates)
     assert rates.max() == 1.0 and rates.min() < 1.0, rates          # accepted and rejected proposals both occurred
+    # A chain that leaves the domain in the MIDDLE of a trajectory (finite potential at the first leapfrog points, undefined
+    # later): the device flags it at that step, skips its momentum kicks from there on and the proposal is rejected -- the same
+    # decisions and the same bits as the host loop, whose evaluations are logged here to prove where the failure happened.
+    class Logged(BatchedHMC):
+        def potential_and_grad(self, q):
+            U, gr = super().potential_and_grad(q)
+            self.log.append(np.isfinite(U).copy())
+            return U, gr
+    eps, L = 5e-3, 6
+    init2 = np.stack([sim.perturb(g["pars"], 0.01 * b, 0.5 * b) for b in range(B)])
+    host = Logged(g["x"], g["Y"], h, init2, step_size=eps, num_steps_in_leap=L, seed=3, device_resident=False)
+    host.log = []
+    sh, ih = host.run(S)
+    log = np.array(host.log[1:]).reshape(S, L, B)
+    first_bad = np.where(log.all(1), L, np.argmin(log, axis=1))       # [S, B]: first undefined leapfrog point of the trajectory
+    assert np.any((first_bad >= 1) & (first_bad < L)), first_bad      # finite at step 0, undefined at an intermediate step
+    dev = BatchedHMC(g["x"], g["Y"], h, init2, step_size=eps, num_steps_in_leap=L, seed=3)
+    sd, idv = dev.run(S)
+    assert np.array_equal(sd, sh) and np.array_equal(idv["accept_rate"], ih["accept_rate"])
+    assert np.array_equal(idv["energy_error"], ih["energy_error"], equal_nan=True)
+    assert np.all(idv["accept_rate"][first_bad.min(0) < L] < 1.0)     # such proposals are never accepted
 
 
 @pytest.mark.gpu
