@@ -331,6 +331,11 @@ void svc_crosscov(hipStream_t st, const double* x, const double* ell, const doub
                   const double* xs, const double* tl_star, const double* Lstar, int S, double* KF);
 void svc_star(hipStream_t st, const double* proj, int S, int M, double mu_l, double mu_L, double* tl_star,
               double* Lstar);
+void svc_crosscov_rows(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M, const double* xs,
+                       const double* tl_star, const double* Lstar, int S, double* A, int ld, int R0);
+// part: 2 * E * ceil(n / 128) doubles
+void pred_rows_reduce(hipStream_t st, const double* A, int ld, int n, int R0, int zrow, int E, double* part, double* mean,
+                      double* colsq);
 void svc_predvar(hipStream_t st, const double* Lstar, const double* colsq, int S, int M, const double* tse,
                  double* var);
 void sep_crossvec(hipStream_t st, int mode, const double* x, const double* sig, const double* ell, int N,

@@ -415,6 +415,87 @@ void svc_crosscov(hipStream_t st, const double* x, const double* ell, const doub
                        S, KF);
 }
 
+// The same cross-covariances written TRANSPOSED below the covariance in the factorisation buffer: row R0 + (s M + m') of the
+// column-major array A (leading dimension ld), column m N + i.  The blocked Cholesky turns every row r below the matrix into
+// r L^-T (as it turns y into z = L^-1 y), so all S M cross-covariance vectors ride along ONE factorisation: no multi-right-hand-side
+// solve afterwards.  Lanes run along the extra-row index (contiguous in a column).
+__global__ __launch_bounds__(256) void k_svc_crosscov_rows(const double* __restrict__ x, const double* __restrict__ ell,
+                                                            const double* __restrict__ Lv, int N, int M, int T,
+                                                            const double* __restrict__ xs, const double* __restrict__ tl_star,
+                                                            const double* __restrict__ Lstar, int S, double* __restrict__ A, int ld,
+                                                            int R0) {
+    const int e = blockIdx.y * 256 + threadIdx.x;          // extra row: grid point s = e / M, output m' = e % M
+    const int i = blockIdx.x;
+    if (e >= S * M) return;
+    const int s = e / M, mp = e - s * M;
+    const double xi = x[i], li = ell[i];
+    const double xj = xs[s], lj = exp(tl_star[s]);
+    const double dist = (xi * xi + xj * xj) - 2.0 * (xi * xj);
+    const double Aij = li * li + lj * lj;
+    const double kv = sqrt(2.0 * (li * lj) / Aij) * exp(-dist / Aij);
+    for (int m = 0; m < M; ++m) {
+        const int rmax = m < mp ? m : mp;
+        double b = 0.0;
+        for (int r = 0; r <= rmax; ++r)
+            b += Lv[(size_t)i * T + m * (m + 1) / 2 + r] * Lstar[(size_t)s * T + mp * (mp + 1) / 2 + r];
+        A[(size_t)(m * N + i) * ld + R0 + e] = kv * b;
+    }
+}
+void svc_crosscov_rows(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M, const double* xs,
+                       const double* tl_star, const double* Lstar, int S, double* A, int ld, int R0) {
+    int T = M * (M + 1) / 2;
+    NMGP_LAUNCH(k_svc_crosscov_rows, dim3(N, cdiv((long long)S * M, 256)), dim3(256), 0, st, x, ell, Lv, N, M, T, xs, tl_star,
+                Lstar, S, A, ld, R0);
+}
+
+// After the factorisation row R0 + e holds v_e = (L^-1 k_e)^T and row zrow z = L^-1 y:  mean[e] = v_e . z (= k_e^T Sigma^-1 y,
+// prediction.py:973) and colsq[e] = |v_e|^2 (the diagonal of T T^T, :975-977).  Columns in chunks of 128 per workgroup (64 rows x 4
+// column groups), partial sums in a fixed order: part[chunk][e][2].
+__global__ __launch_bounds__(256) void k_pred_rows_part(const double* __restrict__ A, int ld, int n, int R0, int zrow, int E,
+                                                         double* __restrict__ part) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.y * 128 + g * 32;
+    double am = 0.0, aq = 0.0;
+    if (e < E) {
+        for (int k = 0; k < 32; ++k) {
+            const int c = c0 + k;
+            if (c < n) {
+                const double v = A[(size_t)c * ld + R0 + e];
+                am = fma(v, A[(size_t)c * ld + zrow], am);
+                aq = fma(v, v, aq);
+            }
+        }
+    }
+    red[0][g][lane] = am;
+    red[1][g][lane] = aq;
+    __syncthreads();
+    if (g == 0 && e < E) {
+        double* o = part + ((size_t)blockIdx.y * E + e) * 2;
+        o[0] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        o[1] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+__global__ __launch_bounds__(256) void k_pred_rows_sum(const double* __restrict__ part, int chunks, int E, double* __restrict__ mean,
+                                                        double* __restrict__ colsq) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    double am = 0.0, aq = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        am += part[((size_t)ch * E + e) * 2];
+        aq += part[((size_t)ch * E + e) * 2 + 1];
+    }
+    mean[e] = am;
+    colsq[e] = aq;
+}
+void pred_rows_reduce(hipStream_t st, const double* A, int ld, int n, int R0, int zrow, int E, double* part, double* mean,
+                      double* colsq) {
+    const int chunks = cdiv(n, 128);
+    NMGP_LAUNCH(k_pred_rows_part, dim3(cdiv(E, 64), chunks), dim3(256), 0, st, A, ld, n, R0, zrow, E, part);
+    NMGP_LAUNCH(k_pred_rows_sum, dim3(cdiv(E, 256)), dim3(256), 0, st, part, chunks, E, mean, colsq);
+}
+
 // GP regression outputs -> starred curves: tl_star[s] = mu_l + proj[s, 0]; uL_star[s, t] = mu_L + proj[s, 1+t];
 // Lstar = uLvec2Lvec(uL_star) (exp on the diagonal slots).  proj: [S, 1+T] column-major (ld = S).
 __global__ void k_svc_star(const double* __restrict__ proj, int S, int M, int T, double mu_l, double mu_L,
