@@ -327,8 +327,6 @@ void sub_vec(hipStream_t s, const double* y, const double* mu, int n, double* ou
 void dot(hipStream_t s, const double* a, const double* b, int n, double* out);
 void kron_eigvec(hipStream_t s, const double* VB, int M, const double* VK, int N, double* U);
 void kron_w(hipStream_t s, const double* wB, int M, const double* wK, int N, double sigma2, double* w);
-void svc_crosscov(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M,
-                  const double* xs, const double* tl_star, const double* Lstar, int S, double* KF);
 void svc_star(hipStream_t st, const double* proj, int S, int M, double mu_l, double mu_L, double* tl_star,
               double* Lstar);
 void svc_crosscov_rows(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M, const double* xs,

@@ -382,41 +382,9 @@ void kron_w(hipStream_t s, const double* wB, int M, const double* wK, int N, dou
 // ---------------------------------------------------------------------------------------------
 // prediction kernels
 // ---------------------------------------------------------------------------------------------
-// KF[(m N + i), (s M + m')] = kx_s[i] (L_i Lstar_s^T)[m, m'],  kx_s[i] = Gibbs(x_i, l_i; xs_s, lstar_s), column-major
-// with leading dimension n = M N (prediction.py:968-972).
-__global__ __launch_bounds__(256) void k_svc_crosscov(const double* __restrict__ x, const double* __restrict__ ell,
-                                                       const double* __restrict__ Lv, int N, int M, int T,
-                                                       const double* __restrict__ xs,
-                                                       const double* __restrict__ tl_star,
-                                                       const double* __restrict__ Lstar, int S,
-                                                       double* __restrict__ KF) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int s = blockIdx.y;
-    if (i >= N) return;
-    const double xi = x[i], li = ell[i];
-    const double xj = xs[s], lj = exp(tl_star[s]);
-    const double dist = (xi * xi + xj * xj) - 2.0 * (xi * xj);
-    const double A = li * li + lj * lj;
-    const double kv = sqrt(2.0 * (li * lj) / A) * exp(-dist / A);
-    const size_t n = (size_t)M * N;
-    for (int m = 0; m < M; ++m)
-        for (int mp = 0; mp < M; ++mp) {
-            const int rmax = m < mp ? m : mp;
-            double b = 0.0;
-            for (int r = 0; r <= rmax; ++r)
-                b += Lv[(size_t)i * T + m * (m + 1) / 2 + r] * Lstar[(size_t)s * T + mp * (mp + 1) / 2 + r];
-            KF[((size_t)s * M + mp) * n + (size_t)m * N + i] = kv * b;
-        }
-}
-void svc_crosscov(hipStream_t st, const double* x, const double* ell, const double* Lv, int N, int M,
-                  const double* xs, const double* tl_star, const double* Lstar, int S, double* KF) {
-    int T = M * (M + 1) / 2;
-    NMGP_LAUNCH(k_svc_crosscov, dim3(cdiv(N, 256), S), dim3(256), 0, st, x, ell, Lv, N, M, T, xs, tl_star, Lstar,
-                       S, KF);
-}
-
-// The same cross-covariances written TRANSPOSED below the covariance in the factorisation buffer: row R0 + (s M + m') of the
-// column-major array A (leading dimension ld), column m N + i.  The blocked Cholesky turns every row r below the matrix into
+// Cross-covariances of the nonseparable model (prediction.py:968-972): k_e[(m N + i)] = kx_s[i] (L_i Lstar_s^T)[m, m'] for grid
+// point s and output m' (e = s M + m'), kx_s[i] = Gibbs(x_i, l_i; xs_s, lstar_s), written TRANSPOSED below the covariance
+// in the factorisation buffer: row R0 + (s M + m') of the column-major array A (leading dimension ld), column m N + i.  The blocked Cholesky turns every row r below the matrix into
 // r L^-T (as it turns y into z = L^-1 y), so all S M cross-covariance vectors ride along ONE factorisation: no multi-right-hand-side
 // solve afterwards.  Lanes run along the extra-row index (contiguous in a column).
 __global__ __launch_bounds__(256) void k_svc_crosscov_rows(const double* __restrict__ x, const double* __restrict__ ell,
