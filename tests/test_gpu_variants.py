@@ -59,7 +59,10 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "va
             {"NMGP_CHOL_LOOKAHEAD": "0"}, {"NMGP_LOOKAHEAD_CUS": "0", "NMGP_CHOL_NB1": "128"}, {"NMGP_PRIOR_OVERLAP": "0"},
             {"NMGP_CHOL_FUSED_MAX_BATCH": "0"}, {"NMGP_PRIOR_SOLVE": "rocblas"},
             {"NMGP_CHOL_FUSE_POTF2": "0"}, {"NMGP_SYRK_SMALL_MAX": "0"}, {"NMGP_SYRK_SMALL_MAX": "100000"},
-            {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"}]
+            {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"},
+            # fused steps under a recursive split (round 3), with the L^-T rows that enter panel by panel; substitution prior solves
+            {"NMGP_CHOL_FUSED_BASE": "128"}, {"NMGP_CHOL_FUSED_BASE": "256", "NMGP_CHOL_PANEL": "fused"},
+            {"NMGP_CHOL_FUSED_BASE": "128", "NMGP_CHOL_PANEL": "fused", "NMGP_POISON": "1"}, {"NMGP_PRIOR_SOLVE": "trsv"}]
 
 
 def run_variant(env_extra):
