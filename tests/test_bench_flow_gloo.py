@@ -176,3 +176,33 @@ def test_subject_workload_two_ranks():
         ref = np.array(O.nlogpos_obj_SVC(sim.perturb(d["pars_true"], 0.05, 0.7), d["Y"], d["x"], **sim.HYPER_SVC_MPISIM,
                                          verbose=True))
         assert np.array_equal(table[s, 3:8], ref)
+
+
+def test_measured_traffic_lookup_is_keyed_by_workload_and_pinned_to_the_kernel_source(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed PMC summaries (profiles/traffic.json): one entry per (N, M, batch, value / value+gradient,
+    workload), reported only while csrc/nmgp_chol.hip still has the SHA-256 it was measured on -- otherwise null with the reason."""
+    sys.path.insert(0, ROOT)
+    import hashlib
+    import bench
+    sha = hashlib.sha256(open(bench.CHOL_SOURCE, "rb").read()).hexdigest()
+    doc = {"entries": [
+        {"N": 2048, "M": 3, "chains": 128, "grad": False, "workload": "chain", "bytes_per_step": 1.0, "source": "a", "chol_sha256": sha},
+        {"N": 2048, "M": 3, "chains": 128, "grad": True, "workload": "chain", "bytes_per_step": 2.0, "source": "b", "chol_sha256": sha},
+        {"N": 1024, "M": 3, "chains": 8, "grad": False, "workload": "subjects", "bytes_per_step": 3.0, "source": "c", "chol_sha256": sha},
+        {"N": 1024, "M": 3, "chains": 64, "grad": False, "workload": "subjects", "bytes_per_step": 4.0, "source": "d",
+         "chol_sha256": "0" * 64}]}
+    f = tmp_path / "traffic.json"
+    f.write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    assert bench.measured_traffic(2048, 3, 128)[0] == 1.0
+    assert bench.measured_traffic(2048, 3, 128, True)[0] == 2.0
+    assert bench.measured_traffic(1024, 3, 8, False, "subjects")[0] == 3.0
+    v, why = bench.measured_traffic(1024, 3, 8, False, "chain")
+    assert v is None and "no committed PMC measurement" in why
+    v, why = bench.measured_traffic(1024, 3, 64, False, "subjects")
+    assert v is None and "stale" in why
+    # the committed file itself: entries for the headline, its value+gradient step and config 4's per-GPU shape
+    monkeypatch.undo()
+    doc = json.load(open(bench.TRAFFIC_FILE))
+    keys = {(e["N"], e["M"], e["chains"], bool(e.get("grad", False)), e.get("workload", "chain")) for e in doc["entries"]}
+    assert {(2048, 3, 128, False, "chain"), (2048, 3, 128, True, "chain"), (1024, 3, 8, False, "subjects")} <= keys
