@@ -450,7 +450,7 @@ def test_rocsolver_and_custom_factorisation_agree_on_the_objective():
     import os
     from nonstationary_multivariate_gaussian_process_amd import _lib
     g = golden("svc_sim_N1024_M3_base")
-    res = {}
+    res, pred = {}, {}
     for algo in ("custom", "rocsolver"):
         os.environ["NMGP_CHOL"] = algo
         try:
@@ -459,7 +459,18 @@ def test_rocsolver_and_custom_factorisation_agree_on_the_objective():
             os.environ.pop("NMGP_CHOL", None)
         c.set_data(g["x"], g["Y"])
         res[algo] = c.logpos_svc(g["pars"], g["hyper"], prior=True, want_grad=True)
+        # prediction through the same context: custom = the cross-covariance rows ride the matrix-core factorisation,
+        # rocsolver = library dpotrf + one right-sided dtrsm on those rows
+        gp = golden("pred_N64_M3")
+        c.set_data(gp["x"], gp["Y"])
+        pred[algo] = c.predict_svc(gp["svc_pars"], gp["svc_hyper"], gp["xs"])
         c.close()
+    ref = gp["svc_pct"]
+    for algo in pred:
+        mean, var, Ls = pred[algo]
+        assert np.allclose(mean, ref[:, 1], rtol=1e-5, atol=1e-7), algo
+        assert np.allclose(var, ((ref[:, 2] - ref[:, 1]) / 1.96) ** 2, rtol=1e-5, atol=1e-9), algo
+    assert np.allclose(pred["custom"][0], pred["rocsolver"][0], rtol=1e-9, atol=1e-11)
     # the likelihood agrees to rounding; the GP-prior terms (condition number ~1e11) agree to their conditioning noise,
     # and both stay within the 1e-6 target of the reference (tools/prior_accuracy.py)
     assert relerr(res["custom"][0][1], res["rocsolver"][0][1]) < 1e-11
