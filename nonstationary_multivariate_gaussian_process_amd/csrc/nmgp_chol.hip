@@ -1494,6 +1494,70 @@ __global__ __launch_bounds__(256, 4) void k_trsm_64f(const double* __restrict__ 
         }
 }
 
+// The same with ONE 16-row chunk per wave (64 rows per workgroup, 84 VGPRs, no spills): six workgroups per CU instead of four.  The
+// solve is bound by HBM at 81 % of what in-place panel accesses reach on this chip; what limits it is how many
+// workgroups of a CU are in their load phase at a time, not the matrix pipe (40 MFMAs per wave against 64 KB moved per workgroup).
+// Measured (same box, alternating): 128 chains 775.4-776.7 -> 779.3-780.3 evals/s, value+gradient 256.4 -> 258.9, 16 chains
+// 667 -> 676, one chain unchanged; with __launch_bounds__(256, 6) the compiler spills 4 registers and half the gain is lost.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_trsm_64h(const double* __restrict__ L, int ldl, double* __restrict__ A, int lda,
+                                                        int rows, long long bstride) {
+    L += (size_t)blockIdx.y * bstride;
+    A += (size_t)blockIdx.y * bstride;
+    __shared__ v4d ops[10][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row = blockIdx.x * 64 + w * 16 + l15;
+    const bool v0 = row < rows;
+    const int rowc = v0 ? row : rows - 1;
+    v4d T[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[q][r] = A[(size_t)(16 * q + 4 * r + l4) * lda + rowc];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        const int idx = tid + 256 * e;
+        const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+        const int rr = l & 15, kc = 4 * kk + (l >> 4);
+        double v;
+        if (blk < 6) {
+            const int q = blk == 0 ? 1 : (blk < 3 ? 2 : 3);
+            const int pp = blk == 0 ? 0 : (blk < 3 ? blk - 1 : blk - 3);
+            v = -L[(size_t)(16 * pp + kc) * ldl + 16 * q + rr];
+        } else {
+            const int q = blk - 6;
+            if (kc < rr) v = L[(size_t)(16 * q + rr) * ldl + 16 * q + kc];
+            else if (kc == rr) v = 1.0 / L[(size_t)(16 * q + rr) * ldl + 16 * q + rr];
+            else v = 0.0;
+        }
+        reinterpret_cast<double*>(&ops[blk][l])[kk] = v;
+    }
+    __syncthreads();
+    if (blockIdx.x * 64 + w * 16 >= rows) return;               // wave-uniform (the MFMAs need every lane)
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        const v4d ai = ops[6 + pp][lane];
+        v4d x0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[kk], T[pp][kk], x0, 0, 0, 0);
+        T[pp] = x0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int q = pp + 1; q < 4; ++q) {
+                const double a = reinterpret_cast<const double*>(&ops[(q == 1 ? 0 : (q == 2 ? 1 : 3)) + pp][lane])[kk];
+                T[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[pp][kk], T[q], 0, 0, 0);
+            }
+    }
+    if (v0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(size_t)(16 * q + 4 * r + l4) * lda + row] = T[q][r];
+    }
+}
+
 static int g_trsm_valu = -1;     // NMGP_TRSM=valu selects the substitution kernel (k_trsm_64)
 static int g_potf2_exports_inv();  // 1 when the block factorisation in use leaves inv(L_qq) in the diagonal blocks
 
@@ -1507,7 +1571,13 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
     if (g_trsm_valu || g_precise) {
         NMGP_LAUNCH(k_trsm_64, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, nb, A, lda, rows, bstride);
     } else if (nb == 64 && g_potf2_exports_inv()) {
-        NMGP_LAUNCH(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
+        // default: one 16-row chunk per wave (k_trsm_64h); NMGP_TRSM=f: two interleaved chunks per wave (k_trsm_64f, the round-2 kernel)
+        static const int two_chunks = [] {
+            const char* e = std::getenv("NMGP_TRSM");
+            return (e && std::strcmp(e, "f") == 0) ? 1 : 0;
+        }();
+        if (!two_chunks) NMGP_LAUNCH(k_trsm_64h<5>, dim3(cdiv_c(rows, 64), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
+        else NMGP_LAUNCH(k_trsm_64f, dim3(cdiv_c(rows, 128), batch), dim3(256), 0, s, L, ldl, A, lda, rows, bstride);
     } else {
         // groups of 128 rows per workgroup: more of them amortise the factor preparation once the launch would fill the
         // chip (512 resident workgroups) several times over anyway

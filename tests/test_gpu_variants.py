@@ -51,7 +51,7 @@ print(json.dumps({"out3": list(map(float, out3)), "grad3": list(map(float, grad3
                   "grad2": list(map(float, grad2)), "batch2": bout2.tolist(), "bgrad2": bgrad2.tolist()}))
 """
 
-VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
+VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "f"}, {"NMGP_POTF2": "valu"}, {"NMGP_TRSM": "valu", "NMGP_POTF2": "valu"},
             {"NMGP_SYRK_YROW": "0"},
             {"NMGP_CHOL_PANEL": "fused"}, {"NMGP_CHOL_PANEL": "rec"}, {"NMGP_CHOL_PANEL": "rl"},
             {"NMGP_CHOL_PANEL": "fused", "NMGP_CHOL_NB1": "128"},
