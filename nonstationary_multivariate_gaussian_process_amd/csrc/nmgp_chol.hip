@@ -1153,6 +1153,8 @@ void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int
         return e ? std::atoi(e) : 256;
     }();
     // (latency regime only: the throughput batches keep one update kernel, whose launches the profiling tools replay)
+    // (round 3 tried the 64x64-tile kernel -- three workgroups per CU -- for the K = 64 / 128 updates of the big batches as well: 128
+    // chains +0.3 % at K <= 64, -0.5 % at K <= 128; not kept)
     if (!ktri && K >= 128 && batch <= 16 && (long long)pl.tiles * batch <= small_max && cs == bstride && (lda & 1) == 0 && mrows >= 2) {
         const int gx = (mrows + 63) / 64, gy = (ncols + 63) / 64;
         int tiles = 0;
