@@ -188,9 +188,16 @@ def dist_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+DIST_ACTIVE = False      # a process group is initialised (world > 1, or one rank under --dist-selftest)
+
+
+def _dist_on(world):
+    return world > 1 or DIST_ACTIVE
+
+
 def barrier(be, ev, world):
     """The bracket of the timed region: all ranks arrive, all device work of this rank is complete."""
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         dist.barrier()
     be.sync()
@@ -198,7 +205,7 @@ def barrier(be, ev, world):
 
 
 def max_over_ranks(elapsed, world, device):
-    if world == 1:
+    if not _dist_on(world):
         return elapsed
     import torch
     import torch.distributed as dist
@@ -209,7 +216,7 @@ def max_over_ranks(elapsed, world, device):
 
 def per_rank(value, world, device):
     """The same scalar of every rank, in rank order (first-contact diagnostics of a multi-GPU run: which rank is the slow one)."""
-    if world == 1:
+    if not _dist_on(world):
         return [float(value)]
     import torch
     import torch.distributed as dist
@@ -226,7 +233,7 @@ def dist_report(be, world, rank_seconds, steps):
            "ms_per_step_max_rank": 1e3 * max(rank_seconds) / max(steps, 1)}
     dc = getattr(be, "device_count", None)
     rep["gpus_visible_to_rank0"] = dc() if dc else None
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         rep["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
     return rep
@@ -534,6 +541,9 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=1,
                     help="split the chains into this many groups, each a batched context on its own pair of HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="with ONE rank: initialise the process group anyway (RCCL) and run the barrier / max / gather / reduction "
+                         "through it -- the part of the multi-GPU path a single-GPU box can execute")
     ap.add_argument("--cpu-evals", type=int, default=5, help="timed value evaluations of the CPU oracle (cpu_baseline; median)")
     ap.add_argument("--cpu-grad-evals", type=int, default=2,
                     help="timed value+gradient evaluations of the CPU oracle (cpu_baseline.grad, next to the `grad` object)")
@@ -548,18 +558,27 @@ def main(argv=None, backend=None):
     if world != a.gpus and world == 1 and a.gpus > 1:
         raise SystemExit("--gpus %d needs a torch.distributed launch (WORLD_SIZE=%d)" % (a.gpus, world))
     be = backend if backend is not None else HipBackend(local_rank)
-    if world > 1:
+    global DIST_ACTIVE
+    if world > 1 or a.dist_selftest:
+        # --dist-selftest: ONE rank initialises the process group as well (RCCL on the HIP backend), so that the barrier, the
+        # max-over-ranks, the per-rank gather and the final reduction run through torch.distributed in the same process as the
+        # library's streams -- what a 1-GPU box can exercise of the multi-GPU path
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
         be.init_dist(rank, world)
+        DIST_ACTIVE = True
     rec, stats, table = (run_subjects if a.workload == "subjects" else run_chains)(a, rank, world, be)
     if rank == 0:
         extra = rec.pop("config_extra", None)
         if extra:
             rec["config"].update(extra)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if DIST_ACTIVE:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+        DIST_ACTIVE = False
     return rec, stats, table
 
 

@@ -54,7 +54,8 @@ def reduce_rows(rows, num_subjects, world_size, device=None):
     per_rank = (num_subjects + world_size - 1) // world_size
     block = np.full((per_rank, ROW), -1.0)
     block[:rows.shape[0]] = rows
-    if world_size == 1 or not dist.is_initialized():
+    # (a single rank with an initialised process group -- bench.py --dist-selftest -- goes through the collectives too)
+    if not (dist.is_available() and dist.is_initialized()):
         table = block
         gathered = [block]
     else:

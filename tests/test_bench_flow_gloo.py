@@ -206,3 +206,14 @@ def test_measured_traffic_lookup_is_keyed_by_workload_and_pinned_to_the_kernel_s
     doc = json.load(open(bench.TRAFFIC_FILE))
     keys = {(e["N"], e["M"], e["chains"], bool(e.get("grad", False)), e.get("workload", "chain")) for e in doc["entries"]}
     assert {(2048, 3, 128, False, "chain"), (2048, 3, 128, True, "chain"), (1024, 3, 8, False, "subjects")} <= keys
+
+
+def test_single_rank_dist_selftest_runs_the_collectives():
+    """--dist-selftest: ONE rank initialises the process group and the barrier, max-over-ranks, per-rank gather and the final
+    reduction go through torch.distributed (gloo here; the GPU twin of this test does it with RCCL next to the library's streams)."""
+    B, steps = 2, 1
+    got = _run(["--gpus", "1", "--steps", str(steps), "--warmup", "0", "--N", str(N), "--M", str(M), "--chains", str(B),
+                "--grad-steps", "0", "--no-cpu-baseline", "--dist-selftest"], world=1)
+    rec = json.loads([ln for ln in got[0][1].splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["distributed"]["process_group"] == {"backend": "gloo", "world_size": 1, "rank": 0}
+    assert rec["config"]["chains_ok"] == B and got[0][3].shape == (B, 8)

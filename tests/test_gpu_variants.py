@@ -125,3 +125,19 @@ def test_factorisation_suite_under_small_tile_and_narrow_panel_settings(env_extr
                           "-x", "-p", "no:cacheprovider", "-k", "custom_cholesky"], capture_output=True, text=True,
                          timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, (env_extra, out.stdout[-3000:])
+
+
+def test_bench_dist_selftest_runs_rccl_next_to_the_library_streams():
+    """`bench.py --dist-selftest` on one GPU: the process group is initialised with the nccl (= RCCL) backend and the barrier, the
+    max-over-ranks all-reduce, the per-rank all-gather and the final reduction run through it in the same process as the library's
+    three streams -- the part of the multi-GPU path (HipBackend.init_dist + collectives on CUDA tensors) a single-GPU box can execute."""
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-selftest", "--chains", "3", "--N", "96", "--steps", "2",
+                          "--warmup", "1", "--grad-steps", "1", "--hmc-samples", "0", "--no-cpu-baseline"], capture_output=True,
+                         text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["distributed"]["process_group"] == {"backend": "nccl", "world_size": 1, "rank": 0}
+    assert rec["config"]["chains_ok"] == 3 and rec["config"]["chain_table_rows"] == 3 and rec["value"] > 0
+    assert rec["grad"]["chains_ok"] == 3
