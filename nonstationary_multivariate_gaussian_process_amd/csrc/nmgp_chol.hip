@@ -395,7 +395,9 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
     const int nyr = (ktri >> 2) & 31;         // rows mrows .. mrows + nyr - 1 (just below the full tiles): see syrk_tile_fast
     const bool skipq = (ktri & 128) != 0;     // the leading 64x64 block of tile (0, 0) belongs to somebody else (k_panel_step)
     const bool mirror = (ktri & 512) != 0;    // also write the strictly upper triangle (C symmetric): beta = 0 launches only
+    const bool rowmajor = (ktri & 1024) != 0; // tile order of the triangular-operand launches: see below
     const int yrow = nyr ? mrows : -1;
+    (void)rowmajor;
     ktri &= 1;
     // rows of L^-T that enter the factorisation with this launch (potrf_lower): the caller describes them by (tri_row0, tri_k0)
     const int fresh0 = tri_row0 == 0x7fffffff ? 0x7fffffff : tri_row0 + tri_k0;
@@ -439,6 +441,25 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
             idx = (int)(g - (long long)bz * tiles_pm);
         }
         const int gx = (mrows + SY_BM - 1) / SY_BM, gy = (ncols + SY_BM - 1) / SY_BM;
+        if (rowmajor) {
+            // Triangular operand (A = L^-T: the k-loop of tile row bi starts at its first row, K_eff = n - 128 bi): tiles differ in
+            // length by up to 48x.  Workgroups are dispatched in id order and id t lands on XCD t % 8, so an XCD that holds longer
+            // tiles than the others makes them wait; the strip order above gives XCD x a whole 8 x 8 block of similar tiles and its
+            // neighbour a block 8 tile rows further down (shorter).  Here the square lower triangle is enumerated row by row
+            // (consecutive ids = consecutive tiles of one tile row = equal length, spread over all XCDs; longest rows first).
+            // (a trapezoid with more tile rows than tile columns: the rows below the triangle have gy tiles each)
+            const int tri = gy * (gy + 1) / 2;
+            if (idx < tri) {
+                int b = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+                while ((b + 1) * (b + 2) / 2 <= idx) ++b;
+                while (b * (b + 1) / 2 > idx) --b;
+                bi = b;
+                bj = idx - b * (b + 1) / 2;
+            } else {
+                bi = gy + (idx - tri) / gy;
+                bj = (idx - tri) % gy;
+            }
+        } else {
         int c0 = 0, W = 0, cnt = 0;
         for (;; c0 += SY_SB) {                       // strip of W tile columns starting at tile column c0
             W = gy - c0 < SY_SB ? gy - c0 : SY_SB;
@@ -462,6 +483,7 @@ __device__ __forceinline__ void syrk_tile_body(const double* __restrict__ A, int
             const int rb = gx - base < SY_SB ? gx - base : SY_SB;
             bj = c0 + in / rb;
             bi = base + in % rb;
+        }
         }
     }
     if (bi < bj) return;
@@ -639,7 +661,8 @@ struct SyrkPlan {
     int tiles = 0;       // valid lower-trapezoid tiles per matrix
 };
 
-static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int batch, int ktri, bool compact_only) {
+static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int batch, int ktri, bool compact_only,
+                          bool tri_rows = false) {
     if (!g_syrk_env) {
         g_syrk_env = 1;
         if (const char* z = std::getenv("NMGP_SYRK_YROW")) g_syrk_yrow = std::atoi(z) != 0;
@@ -674,6 +697,21 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
         }
     }
     pl.kflags = (ktri ? 1 : 0) | (ktri == 2 ? 512 : 0) | yflag;          // ktri = 2: triangular A, C overwritten, both triangles
+    static const int tri_rowmajor = [] {
+        const char* e = std::getenv("NMGP_SYRK_TRI_ORDER");      // strips: the chunked strip order also for triangular operands
+        return (e && std::strcmp(e, "strips") == 0) ? 0 : 1;
+    }();
+    // (measured, 128 chains value+gradient, same box: strips 257.6-258.2 evals/s, row-major for the inverse SYRK only 258.7-259.0,
+    // also for the factorisation's updates with K >= 1024: 262.7-263.1; from K >= 512 / 256 / 64 on: 1.3 / 2.6 / 1.7 evals/s less --
+    // there the tiles of L^-T rows are a small share and the L2 reuse of the strip order is worth more)
+    if ((ktri || (tri_rows && K >= 1024)) && tri_rowmajor && gx >= gy && pl.swz > 0) {
+        // triangular-operand launch (the inverse SYRK; the big updates of a gradient factorisation, whose L^-T rows skip their
+        // leading zero k-panels): tiles of very different length -- row-major order, dealt to the XCDs tile by tile (see
+        // syrk_tile_body)
+        pl.grid = dim3((unsigned)((long long)pl.tiles * batch), 1, 1);
+        pl.swz = -pl.tiles;
+        pl.kflags |= 1024;
+    }
     return pl;
 }
 
@@ -1143,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_syrk_small(const double* __restrict__ A
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride, int ktri, int tri_row0, int tri_k0) {
     if (mrows <= 0 || ncols <= 0 || K <= 0) return;
-    const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false);
+    const SyrkPlan pl = syrk_plan(lda, ldc, mrows, ncols, K, batch, ktri, false, tri_row0 != 0x7fffffff);
     const long long cs = cstride < 0 ? bstride : cstride;
     // few 128x128 tiles (at most one per CU) and a k-loop long enough to matter: 64x64 tiles (k_syrk_small)
     const FuseNext fuse = g_fuse_next;

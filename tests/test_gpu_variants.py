@@ -62,7 +62,8 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "f"}, {"NMGP_POTF2": "valu"
             {"NMGP_POISON": "1"}, {"NMGP_POISON": "1", "NMGP_CHOL_PANEL": "fused"},
             # fused steps under a recursive split (round 3), with the L^-T rows that enter panel by panel; substitution prior solves
             {"NMGP_CHOL_FUSED_BASE": "128"}, {"NMGP_CHOL_FUSED_BASE": "256", "NMGP_CHOL_PANEL": "fused"},
-            {"NMGP_CHOL_FUSED_BASE": "128", "NMGP_CHOL_PANEL": "fused", "NMGP_POISON": "1"}, {"NMGP_PRIOR_SOLVE": "trsv"}]
+            {"NMGP_CHOL_FUSED_BASE": "128", "NMGP_CHOL_PANEL": "fused", "NMGP_POISON": "1"}, {"NMGP_PRIOR_SOLVE": "trsv"},
+            {"NMGP_SYRK_TRI_ORDER": "strips"}]
 
 
 def run_variant(env_extra):
