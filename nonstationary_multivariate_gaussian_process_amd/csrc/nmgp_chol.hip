@@ -704,7 +704,9 @@ static SyrkPlan syrk_plan(int lda, int ldc, int mrows, int ncols, int K, int bat
     // (measured, 128 chains value+gradient, same box: strips 257.6-258.2 evals/s, row-major for the inverse SYRK only 258.7-259.0,
     // also for the factorisation's updates with K >= 1024: 262.7-263.1; from K >= 512 / 256 / 64 on: 1.3 / 2.6 / 1.7 evals/s less --
     // there the tiles of L^-T rows are a small share and the L2 reuse of the strip order is worth more)
-    if ((ktri || (tri_rows && K >= 1024)) && tri_rowmajor && gx >= gy && pl.swz > 0) {
+    // (the inverse SYRK of SMALL batches -- compact enumeration, a few rounds of tiles -- gains most: longest tile rows first is also
+    // the better schedule for the launch's tail; one chain value+gradient 163 -> 168 evals/s, its inverse SYRK 1.47 -> 1.22 ms)
+    if ((ktri || (tri_rows && K >= 1024)) && tri_rowmajor && gx >= gy && (pl.swz > 0 || (ktri && pl.swz < 0))) {
         // triangular-operand launch (the inverse SYRK; the big updates of a gradient factorisation, whose L^-T rows skip their
         // leading zero k-panels): tiles of very different length -- row-major order, dealt to the XCDs tile by tile (see
         // syrk_tile_body)
