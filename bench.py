@@ -346,7 +346,24 @@ def run_chains(a, rank, world, be):
             start = ("the MAP estimate of this subject (tests/golden/%s: %d Adam iterations at lr %.1f by tools/make_map_point.py, "
                      "log posterior %.3f), every chain with its own momenta" % (
                          os.path.basename(mp["path"]), int(mp["iterations"]), float(mp["lr"]), float(mp["target_value_hist"][-1])))
-        hmc = drivers.BatchedHMC(d["x"], d["Y"], hyper, q0, step_size=a.hmc_step, num_steps_in_leap=20, seed=1, ctx=prof)
+        mass_kw, mass_note = {}, "identity mass matrix"
+        if a.hmc_mass != "identity":
+            # a synthetic constant mass matrix of the right SHAPE (rate measurement of the diagonal / dense device path; the
+            # reference derives M = inv(sample covariance) from a previous run, Nonseparable_model_mpiKAISER.py:398-411): M^-1 = s I
+            # (+ a rank-8 term for "dense"), so that the trajectory in q is the identity-mass one at step sqrt(s) eps
+            Pn = q0.shape[1]
+            sc = 4.0
+            if a.hmc_mass == "diag":
+                mass_kw = {"Minv": np.full(Pn, sc)}
+            else:
+                rng = np.random.default_rng(5)
+                W = rng.standard_normal((Pn, 8)) / np.sqrt(Pn)
+                Minv = sc * np.eye(Pn) + sc * (W @ W.T)
+                Mm = (np.eye(Pn) - W @ np.linalg.solve(np.eye(8) + W.T @ W, W.T)) / sc          # Woodbury
+                mass_kw = {"M": Mm, "Minv": Minv}
+            mass_note = "%s mass matrix (synthetic, M^-1 ~ %g I), resident on the device" % (a.hmc_mass, sc)
+        hmc = drivers.BatchedHMC(d["x"], d["Y"], hyper, q0, step_size=a.hmc_step / (2.0 if a.hmc_mass != "identity" else 1.0),
+                                 num_steps_in_leap=20, seed=1, ctx=prof, **mass_kw)
         barrier(be, ev, world)
         t0 = time.perf_counter()
         samples, info = hmc.run(a.hmc_samples)
@@ -356,10 +373,10 @@ def run_chains(a, rank, world, be):
         ee = info["energy_error"]
         moved = float(np.sqrt(np.mean((samples[-1] - q0) ** 2)))
         hmc_rec = {"what": "BatchedHMC: %d chains in lock-step, %d samples per chain, 20 leapfrog steps per sample, step size %g, "
-                           "identity mass matrix (the sampler call of Nonseparable_model.py:228-231, whose step 1e-4 is too coarse at this size: "
+                           "%s (the sampler call of Nonseparable_model.py:228-231, whose step 1e-4 is too coarse at this size: "
                            "profiles/r03_hmc_steps.txt); one batched value+gradient evaluation per leapfrog "
                            "step; positions, momenta and gradients stay in HBM for the whole trajectory (nmgp_svc_batch_traj), per "
-                           "sample the momenta go up and the end point comes down" % (B, a.hmc_samples, a.hmc_step),
+                           "sample the momenta go up and the end point comes down" % (B, a.hmc_samples, a.hmc_step, mass_note),
                    "start": start,
                    "samples_per_s": a.hmc_samples * B * world / h_elapsed, "samples_per_chain": a.hmc_samples,
                    "seconds": h_elapsed, "grad_evals_per_s": evals * world / h_elapsed,
@@ -526,6 +543,10 @@ def parse_args(argv=None):
                     help="leapfrog step size of the `hmc` measurement.  The reference's call uses 1e-4 (Nonseparable_model.py:229); at "
                          "N = 2048 (P = 14,337) that step is rejected almost always from the MAP point (energy error +8.0), 4e-5 is "
                          "accepted 81 %% of the time (energy error 0.39): profiles/r03_hmc_steps.txt")
+    ap.add_argument("--hmc-mass", choices=["identity", "diag", "dense"], default="identity",
+                    help="mass matrix of the `hmc` measurement: identity (default, the call of Nonseparable_model.py:228-231), or a "
+                         "synthetic diagonal / dense one resident on the device (nmgp_svc_batch_traj_set_mass; dense: P x P = 1.6 GB "
+                         "at the headline size, one GEMM per leapfrog step for all chains; the host factors M once: ~1 min)")
     ap.add_argument("--hmc-samples", type=int, default=5,
                     help="samples per chain of the BatchedHMC end-to-end measurement reported in the `hmc` object (0 = skip)")
     ap.add_argument("--workload", choices=["chain", "subjects"], default="chain",
