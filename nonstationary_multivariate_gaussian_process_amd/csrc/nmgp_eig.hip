@@ -833,7 +833,7 @@ static int gp_project(nmgp_ctx* c, PriorFactor* pf, const double* d_xs, int S, c
     // W = Sigma^-1 K* through the cached Cholesky factor (S right-hand sides).  By substitution (k_prior_trsv: true divisions,
     // one workgroup per right-hand side): the library's trsm multiplies by INVERTED 128 x 128 diagonal blocks, which costs
     // digits on a factor of condition number ~1e5.5 (NMGP_PRIOR_SOLVE=rocblas selects it; sizes beyond the kernel's LDS too)
-    if (N <= 3500 && !c->prior_rocblas) {
+    if (N <= 15000 && !c->prior_rocblas) {        // (the right-hand side lives in LDS: 8 N + 34 KB of the CU's 160 KB)
         prior_trsv(s, false, pf->L, pf->ld, 0, pf->L, pf->ld, 0, Ks, N, S, 1);
         prior_trsv(s, true, pf->L, pf->ld, 0, pf->L, pf->ld, 0, Ks, N, S, 1);
     } else {
@@ -956,6 +956,54 @@ static int eig_predict(nmgp_ctx* c, EigWork& w, double sigma2, int mode, const d
     return 0;
 }
 
+// The same predictor through the Cholesky formulation (the default of the objectives, NMGP_SEP=eig selects the eigen one above):
+// M blocks S_p = wB[p] K + sigma2 I as ONE batch of the blocked factorisation, the rotated data yt_p and the S cross-covariance
+// vectors riding below every block as extra rows (rows become r L_p^-T) -- no eigendecomposition of K_x (133 ms at N = 4096), no
+// triangular solve.  c->d_K holds the lower triangle of K_x and survives.
+static int chol_predict(nmgp_ctx* c, EigWork& w, double sigma2, int mode, const double* d_xs, const double* tl_star,
+                        const double* ts_star, double sig0, double l0, const double* d_kss, bool strict_clip, int S, double* mean,
+                        double* var) {
+    const int N = c->N, M = c->M;
+    hipStream_t s = c->stream;
+    const int smax = std::max(1, N - 2), Sm = std::min(S, smax);
+    const int ld = (int)((((size_t)N + 1 + Sm + 15) / 16) * 16);
+    const long long bs = (long long)ld * N;
+    double *KX, *Sbuf, *sm, *part;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG2, (size_t)N * S, &KX));
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, (size_t)M * bs, &Sbuf));
+    NMGP_TRY(nmgp_scratch_get(c, SL_U, (size_t)2 * S * M + M + (size_t)2 * M * S + 16, &sm));
+    NMGP_TRY(nmgp_scratch_get(c, SL_PART, (size_t)2 * Sm * ((N + 127) / 128), &part));
+    double *d_mean = sm, *d_var = sm + (size_t)S * M, *d_Bdiag = d_var + (size_t)S * M, *dots = d_Bdiag + M, *sqs = dots + (size_t)M * S;
+    int* info = reinterpret_cast<int*>(sqs + (size_t)M * S);
+    std::vector<double> bd(M);
+    for (int m = 0; m < M; ++m) bd[m] = w.h_B[(size_t)m * M + m];
+    HIP_TRY(c, hipMemcpyAsync(d_Bdiag, bd.data(), M * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(info, 0, (size_t)M * sizeof(int), s));
+    sep_crossvec(s, mode, c->d_x, c->d_sig, c->d_ell, N, d_xs, tl_star, ts_star, sig0, l0, S, KX);
+    double* yt = w.a;                                              // [M, N]: yt_p = (V_B^T kron I) y
+    rotate_y(s, c->d_Y, w.VB, N, M, yt);
+    for (int s0 = 0; s0 < S; s0 += smax) {
+        const int Sc = std::min(smax, S - s0);
+        sep_blocks(s, c->d_K, w.wB, w.sig2, N, M, Sbuf, ld, bs);
+        set_row(s, Sbuf, ld, N, yt, N, M, bs, N);
+        cols_to_rows(s, KX + (size_t)s0 * N, N, Sc, Sbuf, ld, N + 1, M, bs);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, N), Sbuf, ld, N, 1 + Sc, 0, c->chol_nb1, info, M, bs, 1, nmgp_syrk_hook(c));
+        for (int p = 0; p < M; ++p)
+            pred_rows_reduce(s, Sbuf + (size_t)p * bs, ld, N, N + 1, N, Sc, part, dots + (size_t)p * S + s0, sqs + (size_t)p * S + s0);
+    }
+    sep_predict_chol(s, dots, sqs, w.wB, w.VB, M, sigma2, d_Bdiag, d_kss, strict_clip, S, d_mean, d_var);
+    std::vector<int> hi(M);
+    HIP_TRY(c, hipMemcpyAsync(mean, d_mean, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(var, d_var, (size_t)S * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    NMGP_TRY(nmgp_take_launch_error(c));
+    for (int p = 0; p < M; ++p)
+        if (hi[p] != 0)
+            return nmgp_fail(c, hi[p], "block %d of the separable covariance is not positive definite (leading minor %d)", p, hi[p]);
+    return 0;
+}
+
 extern "C" int nmgp_predict_sep(nmgp_ctx* c, const double* pars, const double hyper[9], const double* xs, int S,
                                 double* mean, double* var) {
     if (!c) return NMGP_E_NULL;
@@ -993,7 +1041,7 @@ extern "C" int nmgp_predict_sep(nmgp_ctx* c, const double* pars, const double hy
     exp_vec(s, c->d_pars, N, c->d_ell);
     exp_vec(s, c->d_pars + N, N, c->d_sig);
     gibbs_cov_sym(s, c->d_x, c->d_sig, c->d_ell, N, c->d_K, N, false);
-    return eig_predict(c, w, sigma2, 0, d_xs, tl_star, ts_star, 0.0, 1.0, d_kss, false, S, mean, var);
+    return (c->sep_algo == 1 ? chol_predict : eig_predict)(c, w, sigma2, 0, d_xs, tl_star, ts_star, 0.0, 1.0, d_kss, false, S, mean, var);
 }
 
 extern "C" int nmgp_predict_sta(nmgp_ctx* c, const double* pars, const double* xs, int S, double* mean, double* var) {
@@ -1017,5 +1065,5 @@ extern "C" int nmgp_predict_sta(nmgp_ctx* c, const double* pars, const double* x
     jacobi_eigh(M, w.h_B.data(), w.h_wB, w.h_VB);
     NMGP_TRY(setup_small(c, w, M, N, sigma2));
     rbf_cov_sym(s, c->d_x, N, sig0, l0, c->d_K, N, false);                // RBF_cov(x, alpha=sigma, beta=l) (:1587)
-    return eig_predict(c, w, sigma2, 1, d_xs, nullptr, nullptr, sig0, l0, d_kss, true, S, mean, var);
+    return (c->sep_algo == 1 ? chol_predict : eig_predict)(c, w, sigma2, 1, d_xs, nullptr, nullptr, sig0, l0, d_kss, true, S, mean, var);
 }

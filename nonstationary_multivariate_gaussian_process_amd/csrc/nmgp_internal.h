@@ -342,6 +342,9 @@ void sep_crossvec(hipStream_t st, int mode, const double* x, const double* sig, 
 void sep_predict(hipStream_t st, const double* Cq, const double* a, const double* wB, const double* VB, int M,
                  const double* wK, int N, double sigma2, const double* Bdiag, const double* kss, bool strict_clip, int S,
                  double* mean, double* var);
+void sep_predict_chol(hipStream_t st, const double* dots, const double* sqs, const double* wB, const double* VB, int M, double sigma2,
+                      const double* Bdiag, const double* kss, bool strict_clip, int S, double* mean, double* var);
+void cols_to_rows(hipStream_t st, const double* KX, int N, int S, double* A, int ld, int R0, int batch, long long bstride);
 void sep_star(hipStream_t st, const double* proj, int S, double mu_l, double mu_s, double* tl_star, double* ts_star,
               double* kss);
 void add_diag(hipStream_t s, double* A, int ld, int n, double v);

@@ -1027,6 +1027,15 @@ void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long 
                 double* R, int N, int nrhs, int batch, int cps) {
     const size_t lds = ((size_t)N + 2 + 64 * 65 + 64) * sizeof(double);
     if (cps < 1) cps = 1;
+    if (lds > 64 * 1024) {
+        // beyond the default 64 KB of dynamic LDS (N > 3966): opt in to the CU's 160 KB once (prediction at config 5's N = 4096)
+        static bool raised = false;
+        if (!raised) {
+            raised = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+    }
     if (trans)
         NMGP_LAUNCH(k_prior_trsv<true>, dim3(nrhs, batch), dim3(1024), lds, s, L0, ld0, s0, L1, ld1, s1, R, N, nrhs, cps);
     else

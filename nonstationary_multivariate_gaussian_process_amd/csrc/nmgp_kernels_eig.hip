@@ -583,6 +583,47 @@ void sep_predict(hipStream_t st, const double* Cq, const double* a, const double
                        strict_clip ? 1 : 0, mean, var);
 }
 
+// The Cholesky formulation of the same moments (B kron K + sigma2 I = (V_B kron I) blockdiag_p(S_p) (V_B^T kron I), S_p = wB[p] K +
+// sigma2 I): the cross-covariance vectors kx_s ride every block's factorisation as extra rows, so that after it
+//   dots[p, s] = (L_p^-1 kx_s) . (L_p^-1 yt_p) = kx_s^T S_p^-1 yt_p,    sqs[p, s] = |L_p^-1 kx_s|^2 = kx_s^T S_p^-1 kx_s, and
+//   mean[s, m] = sum_p wB[p] VB[m, p] dots[p, s],   var[s, m] = B[m, m] kss[s] - sum_p (wB[p] VB[m, p])^2 sqs[p, s] + sigma2.
+__global__ void k_sep_predict_chol(const double* __restrict__ dots, const double* __restrict__ sqs, const double* __restrict__ wB,
+                                   const double* __restrict__ VB, int M, double sigma2, const double* __restrict__ Bdiag,
+                                   const double* __restrict__ kss, int strict_clip, int S, double* __restrict__ mean,
+                                   double* __restrict__ var) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S * M) return;
+    const int s = k / M, m = k - s * M;
+    double mu = 0.0, vv = 0.0;
+    for (int p = 0; p < M; ++p) {
+        const double am = wB[p] * VB[m * M + p];
+        mu += am * dots[(size_t)p * S + s];
+        vv += (am * am) * sqs[(size_t)p * S + s];
+    }
+    double v = (Bdiag[m] * kss[s] - vv) + sigma2;
+    if (strict_clip ? (v < 0.0) : (v <= 0.0)) v = NMGP_PRECISION;
+    mean[k] = mu;
+    var[k] = v;
+}
+void sep_predict_chol(hipStream_t st, const double* dots, const double* sqs, const double* wB, const double* VB, int M, double sigma2,
+                      const double* Bdiag, const double* kss, bool strict_clip, int S, double* mean, double* var) {
+    NMGP_LAUNCH(k_sep_predict_chol, dim3(cdiv((long long)S * M, 256)), dim3(256), 0, st, dots, sqs, wB, VB, M, sigma2, Bdiag, kss,
+                strict_clip ? 1 : 0, S, mean, var);
+}
+
+// rows R0 .. R0 + S - 1 of every matrix of a batch := the columns of KX ([N, S] column-major): A[b][i * ld + R0 + s] = KX[s N + i]
+// (the same S vectors below each of the M blocks); lanes along s
+__global__ __launch_bounds__(256) void k_cols_to_rows(const double* __restrict__ KX, int N, int S, double* __restrict__ A, int ld,
+                                                       int R0, long long bstride) {
+    const int s = blockIdx.y * 256 + threadIdx.x;
+    const int i = blockIdx.x;
+    if (s >= S) return;
+    A[(size_t)blockIdx.z * bstride + (size_t)i * ld + R0 + s] = KX[(size_t)s * N + i];
+}
+void cols_to_rows(hipStream_t st, const double* KX, int N, int S, double* A, int ld, int R0, int batch, long long bstride) {
+    NMGP_LAUNCH(k_cols_to_rows, dim3(N, cdiv(S, 256), batch), dim3(256), 0, st, KX, N, S, A, ld, R0, bstride);
+}
+
 // starred scalars of the separable model: tl_star = mu_l + proj[:,0], ts_star = mu_s + proj[:,1],
 // kss[s] = exp(ts_star)^2 + jitter (Gibbs kernel of the new point with itself, prediction.py:393-397)
 __global__ void k_sep_star(const double* __restrict__ proj, int S, double mu_l, double mu_s,

@@ -410,6 +410,42 @@ def test_batch_with_two_different_prior_factors_equals_single_chain_evaluations(
         assert vec_relerr(grads[b], singles[b][1]) < 1e-10
 
 
+def test_separable_prediction_at_config5_size_against_the_oracle(ctx):
+    """Config 5's shape (separable, N = 4096, D = 5): the predictor through the Cholesky formulation -- five N x N blocks as one batch,
+    the cross-covariance vectors riding as extra rows, GP regressions of l~* and sigma~* by substitution (the right-hand side in
+    more than 64 KB of LDS) -- against the CPU oracle's eigen formulation (prediction.py:337-408) on a few grid points; and the
+    library's own eigen formulation (NMGP_SEP=eig) on the same inputs."""
+    import os
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    from oracle import nmgp_oracle as O
+    N, M = 4096, 5
+    d = sim.simulate_separable(N, M, seed=8)
+    p = d["pars_true"].copy()
+    p[:N] += 0.05 * np.sin(3.0 * d["x"] + 0.4)
+    h = sim.HYPER_SEP
+    hv = [h[k] for k in SEP_KEYS]
+    xs = np.array([0.0, 0.013, 0.2, 0.37, 0.5, 0.613, 0.88, 1.0])
+    ctx.set_data(d["x"], d["Y"])
+    mean, var = ctx.predict_sep(p, hv, xs)
+    tl, ts, uLv, tse = O.vec2pars(p, N, M)
+    _, mo, vo = O.predmap_separable(tl, ts, uLv, tse, d["Y"], d["x"], xs, h["mu_tilde_l"], h["alpha_tilde_l"], h["beta_tilde_l"],
+                                    h["mu_tilde_sigma"], h["alpha_tilde_sigma"], h["beta_tilde_sigma"])
+    record_parity("pred_sep_N4096_M5_oracle", mean=(float(np.max(np.abs(mean - mo) / (1e-7 + 1e-5 * np.abs(mo)))) * 1e-5, 1e-5),
+                  var=(float(np.max(np.abs(var - vo) / vo)), 1e-5))
+    assert np.allclose(mean, mo, rtol=1e-5, atol=1e-7) and np.allclose(var, vo, rtol=1e-5, atol=1e-9)
+    os.environ["NMGP_SEP"] = "eig"
+    try:
+        c2 = _lib.Context(0)
+    finally:
+        os.environ.pop("NMGP_SEP", None)
+    try:
+        c2.set_data(d["x"], d["Y"])
+        m2, v2 = c2.predict_sep(p, hv, xs)
+    finally:
+        c2.close()
+    assert np.allclose(mean, m2, rtol=1e-7, atol=1e-9) and np.allclose(var, v2, rtol=1e-6, atol=1e-10)
+
+
 # ---------------------------------------------------------------------------------------------------
 # custom blocked Cholesky (nmgp_chol.hip): FP64-MFMA SYRK, 64-wide panel steps, right-hand side as an extra row
 # ---------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Deterministic prediction at the reference's grid (Nonseparable_model.py:333: 201 points) -- accuracy against the committed
 reference golden (N = 512) and wall time at the headline size (N = 2048, D = 3).
-    python tools/pred_bench.py [N for the timing, default 2048] [grid points, default 201] [repetitions, default 5]
+    python tools/pred_bench.py [N for the timing, default 2048] [grid points, default 201] [repetitions, default 5] [N_sep D_sep]
 Prints one JSON line.  Under `rocprofv3 --kernel-trace --stats` the per-kernel table gives k_svc_crosscov's duration; its
 algorithmic traffic is the cross-covariance it writes, 8 n S M bytes (n = N M), quoted in the line."""
 import json
@@ -60,6 +60,32 @@ def main():
                      "ms_median": 1e3 * float(np.median(ts)), "ms_min": 1e3 * float(np.min(ts)),
                      "crosscov_algorithmic_bytes": 8.0 * n * S * M, "mean_finite": bool(np.all(np.isfinite(mean))),
                      "var_positive": bool(np.all(var > 0))}
+    # separable (config 5's shape when N = 4096, D = 5) and stationary predictors on the same grid: one eigendecomposition of K_x
+    # for all grid points (the reference: one per grid point, prediction.py:381-382)
+    if len(sys.argv) > 4:
+        Ns, Ms = int(sys.argv[4]), int(sys.argv[5]) if len(sys.argv) > 5 else 5
+        ds = sim.simulate_separable(Ns, Ms, seed=8)
+        hs = np.array([sim.HYPER_SEP[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma",
+                                                   "beta_tilde_sigma", "a", "b", "c")])
+        c.set_data(ds["x"], ds["Y"])
+        c.predict_sep(ds["pars_true"], hs, xs)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            m2, v2 = c.predict_sep(ds["pars_true"], hs, xs)
+            ts.append(time.perf_counter() - t0)
+        rec["timing_sep"] = {"what": "nmgp_predict_sep, N=%d, D=%d, %d grid points" % (Ns, Ms, S), "ms_median": 1e3 * float(np.median(ts)),
+                             "finite": bool(np.all(np.isfinite(m2)) and np.all(v2 > 0))}
+        dt_ = sim.simulate_stationary(Ns, Ms, seed=8)
+        c.set_data(dt_["x"], dt_["Y"])
+        c.predict_sta(dt_["pars_true"], xs)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            m3, v3 = c.predict_sta(dt_["pars_true"], xs)
+            ts.append(time.perf_counter() - t0)
+        rec["timing_sta"] = {"what": "nmgp_predict_sta, N=%d, D=%d, %d grid points" % (Ns, Ms, S), "ms_median": 1e3 * float(np.median(ts)),
+                             "finite": bool(np.all(np.isfinite(m3)) and np.all(v3 > 0))}
     print(json.dumps(rec))
     c.close()
 
