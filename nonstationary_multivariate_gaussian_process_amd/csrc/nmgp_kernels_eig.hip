@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void k_kron_mv(const double* __restrict__ K, i
 #pragma unroll
         for (int b = 0; b < KMV_CH; ++b) acc[b] = 0.0;
         if (VEC2) {
-            // 16 bytes per lane, four independent row segments in flight per lane (1 KiB per wave instruction)
+            // 16 bytes per lane, four independent row segments in flight per lane (1 KiB per wave instruction).
+            // (Round 3 tried, at N = 4096, D = 5, where this launch takes 43-46 us = 3.0 TB/s: 8 and 32 segments in flight per lane
+            // -- 43 and 93 us --, four rows per workgroup sharing their y loads -- 49 us --, and per-row start offsets staggered
+            // against the power-of-two row stride -- 52 us.  Neither the bytes a wave keeps in flight, nor the L2 re-reads of y, nor
+            // channel conflicts bound it; it runs once per evaluation of the eigen formulation, next to a 133 ms dsyevd.)
             const int n2h = n2 >> 1;
             const double2* row2 = reinterpret_cast<const double2*>(row);
             int c = lane;
