@@ -1657,11 +1657,30 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 #define PS_XS_OFF (PS_XPS_OFF + 64 * PS_XLD)
 #define PS_SMEM_DOUBLES (PS_XS_OFF + 64 * PS_XLD)        // 15104 doubles = 118 KB (the factorisation's LDS aliases the operands)
 
-__global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev, int has_next,
+// MODE 0: the general step.  MODE 1 / 2: the two steps of a 128-column LEAF of the throughput schedule (big batches: recursive
+// halving down to 128 columns, then these two launches instead of diagonal block + solve + K = 64 update + diagonal block + solve:
+// the K = 64 update is folded into the second step's solve, 5 passes over the rows' column blocks instead of 7):
+//   MODE 1 = first step  (no previous block, a next one; no update role, no P waves): solve + the critical workgroup's D and its
+//            factorisation; 54 KB of LDS;
+//   MODE 2 = second step (a previous block, no next one): catch-up + solve; 52 KB of LDS.
+// With the flags known at compile time at most two 64-column row blocks are live per thread: 128 VGPRs, two workgroups per CU, so
+// that one's loads travel under the other's MFMAs and stores (the general step holds three blocks in 208 VGPRs, one per CU).
+template <int MODE>
+__global__ __launch_bounds__(512, MODE ? 4 : 2) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev_a,
+                                                        int has_next_a,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
-                                                        int u_tiles, int nbatch, int pre, int un_fresh, int u_tri,
+                                                        int u_tiles, int nbatch, int pre_a, int un_fresh, int u_tri,
                                                         long long* __restrict__ stamps) {
+    const int has_prev = MODE == 0 ? has_prev_a : (MODE == 2 ? 1 : 0);
+    const int has_next = MODE == 0 ? has_next_a : (MODE == 1 ? 1 : 0);
+    const int pre = MODE == 0 ? pre_a : 0;
+    constexpr int kOpsT = MODE == 1 ? 0 : 4096;                         // doubles; MODE 1 stages no catch-up operands (opsC)
+    constexpr int kXps = PS_XPS_OFF;                                    // (MODE 0 only)
+    constexpr int kXs = MODE == 1 ? 2560 : PS_XS_OFF;
+    constexpr int kSmem = MODE == 1 ? 2560 + 64 * PS_XLD
+                                    : (MODE == 2 ? 6656 : (PS_SMEM_DOUBLES > 4 * SY_BK * SY_LD ? PS_SMEM_DOUBLES : 4 * SY_BK * SY_LD));
+    static_assert(MODE != 1 || sizeof(Potf2Lds) <= kSmem * sizeof(double), "the factorisation's LDS aliases the step's");
     // un_fresh / u_tri (gradient evaluations; 0x7fffffff otherwise): rows >= un_fresh (absolute) are rows of L^-T whose
     // entries in column block k + 1 nobody has written yet (they start from zero); u_tri = the same boundary for the update
     // role, relative to its C origin (see potrf_lower on "fresh" rows)
@@ -1672,7 +1691,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
         if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = (long long)wall_clock64(); \
     } while (0)
     PS_STAMP(0);
-    __shared__ __attribute__((aligned(32))) double smem[PS_SMEM_DOUBLES > 4 * SY_BK * SY_LD ? PS_SMEM_DOUBLES : 4 * SY_BK * SY_LD];
+    __shared__ __attribute__((aligned(32))) double smem[kSmem];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // 1-D grid, role-major: workgroup id = role index * nbatch + matrix.  The dispatcher hands out workgroups in id order,
@@ -1682,19 +1701,21 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     const int bx = (int)blockIdx.x / nbatch, by = (int)blockIdx.x - bx * nbatch;
     if (bx >= T) {
         // ---- update role: one 128x128 tile of the delayed K = 64 update of the remaining panel columns ----
-        const int t = bx - T + by * u_tiles;       // compact tile index over the batch
-        const double* Ap = Ab + (size_t)(ck - 64) * lda + (ck + 128);
-        double* Cp = Ab + (size_t)(ck + 128) * lda + (ck + 128);
-        syrk_tile_body<4, SY_BK>(Ap, lda, Cp, lda, u_mrows, u_ncols, 64, bstride, bstride, u_kflags, -u_tiles, nbatch, t, 0,
-                                 0, smem, smem + 2 * SY_BK * SY_LD, u_tri, 0);
+        if constexpr (MODE == 0) {
+            const int t = bx - T + by * u_tiles;       // compact tile index over the batch
+            const double* Ap = Ab + (size_t)(ck - 64) * lda + (ck + 128);
+            double* Cp = Ab + (size_t)(ck + 128) * lda + (ck + 128);
+            syrk_tile_body<4, SY_BK>(Ap, lda, Cp, lda, u_mrows, u_ncols, 64, bstride, bstride, u_kflags, -u_tiles, nbatch, t, 0,
+                                     0, smem, smem + 2 * SY_BK * SY_LD, u_tri, 0);
+        }
         return;
     }
     // ---- solve role ----
     double* A = Ab + (size_t)by * bstride;
     v4d* opsC = reinterpret_cast<v4d*>(smem);                    // [4 q][4 sg][64 lanes]: -L[cb + 16 q + i][4 (4 sg + kk) + l4]
-    v4d* opsT = reinterpret_cast<v4d*>(smem + 4096);             // [10][64 lanes], as in k_trsm_64f
-    double* Xps = smem + PS_XPS_OFF;                             // [64][PS_XLD]: X[k+1, k-1] (workgroup 0)
-    double* Xs = smem + PS_XS_OFF;                               // [64][PS_XLD]: X[k+1, k]   (workgroup 0)
+    v4d* opsT = reinterpret_cast<v4d*>(smem + kOpsT);            // [10][64 lanes], as in k_trsm_64f
+    double* Xps = smem + (MODE == 0 ? kXps : 0);                 // [64][PS_XLD]: X[k+2, k-1] (the P waves; MODE 0 only)
+    double* Xs = smem + (MODE == 2 ? 0 : kXs);                   // [64][PS_XLD]: X[k+1, k]   (workgroup 0; not in MODE 2)
     // Workgroup 0 owns the critical block row k + 1 ("C", waves 0..3: its diagonal block is factored at the end of this
     // launch) and nothing else: its waves 4..7 only take part in the barriers.  The FP64 matrix pipe of a SIMD is shared by
     // the waves on it, and the ~230 MFMAs per wave that lead up to the factorisation ARE the critical path; a second block
@@ -1711,6 +1732,9 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     const int row = wg0 ? ck + 64 + 16 * w + l15 : ck + 128 + 128 * (bx - 1) + 16 * w + l15;
     const bool rv = row < m_act && !(wg0 && w >= 4);
     const int rowc = row < m_act ? row : (m_act - 1);            // clamped: loads stay in bounds, results are masked
+    // column block k + 1 of this thread's row: the critical workgroup needs it for D, the others for its catch-up with column
+    // block k - 1 -- in the first step of a panel (no k - 1) they neither read nor write it
+    const bool un_used = has_next && (has_prev || wg0);
     // (1) issue every global load this thread needs up front
     double oc[8], ot[5];
     v4d Xp[4], Tk[4], Un[4];
@@ -1750,7 +1774,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
             const int c = 16 * q + 4 * r + l4;
             Tk[q][r] = rv ? A[(size_t)(ck + c) * lda + rowc] : 0.0;
             Xp[q][r] = (rv && has_prev) ? Lp[(size_t)c * lda + rowc] : 0.0;
-            Un[q][r] = (rv && has_next && row < un_fresh) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
+            Un[q][r] = (rv && un_used && row < un_fresh) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
         }
     // (2) operands to LDS
     if (has_prev) {
@@ -1770,7 +1794,7 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
     for (int j = 0; j < 5; ++j) {
         const int idx = tid + 512 * j;
         const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
-        smem[4096 + (blk * 64 + l) * 4 + kk] = ot[j];
+        smem[kOpsT + (blk * 64 + l) * 4 + kk] = ot[j];
     }
     __syncthreads();
     PS_STAMP(1);
@@ -1847,7 +1871,8 @@ __global__ __launch_bounds__(512) void k_panel_step(double* __restrict__ Ab, int
                         Un[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Xp[sg][kk], Un[q], 0, 0, 0);
                     }
         }
-        if (rv) {
+        // (first step of a panel: only the rows of L^-T that enter with it -- their zeros are what the next step's solve loads)
+        if (rv && (has_prev || row >= un_fresh)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -2036,7 +2061,7 @@ static int g_stamps_cap = 0;
 static const char* g_stamps_path = nullptr;
 
 static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
-                               int batch, long long bs, int is) {
+                               int batch, long long bs, int is, bool leaf = false) {
     if (!g_first_block_done)                                                       // the panel's first diagonal block
         potf2_64(s, A + (size_t)c0 * lda + c0, lda, 64, info, c0, batch, bs, is);  // (unless the near update factored it)
     g_first_block_done = 0;
@@ -2059,8 +2084,17 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         // solve role of that step and of the next one, everything further right by the update role one step later
         const int un_fresh = xtri > 0 ? n + extra + (has_prev ? ck - 64 : ck) : 0x7fffffff;
         const int u_tri = xtri > 0 ? n + extra - 192 : 0x7fffffff;
-        NMGP_LAUNCH(k_panel_step, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act, c0 + w, bs,
-                    info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, un_fresh, u_tri, st);
+        if (leaf && pl.tiles == 0 && !pre && nk == 2) {
+            if (k == 0)
+                NMGP_LAUNCH(k_panel_step<1>, dim3((unsigned)(T * batch)), dim3(512), 0, s, A, lda, ck, 0, 1, m_act, c0 + w, bs, info, is, T,
+                            0, 0, 0, 0, batch, 0, un_fresh, u_tri, st);
+            else
+                NMGP_LAUNCH(k_panel_step<2>, dim3((unsigned)(T * batch)), dim3(512), 0, s, A, lda, ck, 1, 0, m_act, c0 + w, bs, info, is, T,
+                            0, 0, 0, 0, batch, 0, un_fresh, u_tri, st);
+        } else {
+            NMGP_LAUNCH(k_panel_step<0>, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act,
+                        c0 + w, bs, info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, un_fresh, u_tri, st);
+        }
     }
 }
 
@@ -2088,15 +2122,21 @@ static bool panel_takes_fused_steps(int n, int w, int lda, int batch) {
 // halved recursively (one K = w/2 update per level, ordinary update kernel with the next diagonal block fused) until the
 // pieces are `base` wide, and only those run as fused steps: base = 128 keeps recursive halving's 768 passes with 11 launches
 // per 512 columns instead of 23.  NMGP_CHOL_FUSED_BASE=<128|256|512|...>; auto: fused_base_width() below.
+static void factor_panel_rec(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
+                             int batch, long long bs, int is);
+
 static void factor_panel_fused_split(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int base,
-                                     int* info, int batch, long long bs, int is) {
+                                     int* info, int batch, long long bs, int is, bool leaf = false) {
     if (w <= base) {
-        factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+        // leaf = the throughput schedule: 128-column pieces take the two leaf launches (k_panel_step<1>, <2>), a 64-column
+        // remainder the plain diagonal block + solve
+        if (leaf && w != 128) factor_panel_rec(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
+        else factor_panel_fused(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is, leaf);
         return;
     }
     int h = ((w / 2 + 63) / 64) * 64;
     if (h >= w) h = ((w - 1) / 64) * 64;
-    factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, h, base, info, batch, bs, is);
+    factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, h, base, info, batch, bs, is, leaf);
     const int c1 = c0 + h;
     const int below = active_rows(n, extra, xtri, c1) - c1;
     if (below > 0) {
@@ -2105,7 +2145,7 @@ static void factor_panel_fused_split(hipStream_t s, double* A, int lda, int n, i
                    xtri > 0 ? n + extra - c1 : 0x7fffffff, c0);
         g_fuse_next.info = nullptr;
     }
-    factor_panel_fused_split(s, A, lda, n, extra, xtri, c1, w - h, base, info, batch, bs, is);
+    factor_panel_fused_split(s, A, lda, n, extra, xtri, c1, w - h, base, info, batch, bs, is, leaf);
 }
 
 static int fused_base_width(int n, int extra, int xtri, int c0, int w, int batch) {
@@ -2127,8 +2167,17 @@ static int fused_base_width(int n, int extra, int xtri, int c0, int w, int batch
 static void factor_panel(hipStream_t s, double* A, int lda, int n, int extra, int xtri, int c0, int w, int* info,
                          int batch, long long bs, int is) {
     const int rec_min_batch = 4;                 // smallest batch that takes the recursive panels
+    // NMGP_CHOL_LEAF=0: the throughput schedule's 128-column pieces as five launches (diagonal block, solve, K = 64 update with
+    // the next diagonal block, solve) instead of the two leaf launches
+    static const int leaf_on = [] {
+        const char* e = std::getenv("NMGP_CHOL_LEAF");
+        return e ? std::atoi(e) : 1;
+    }();
     if (panel_takes_fused_steps(n, w, lda, batch))
         factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, w, fused_base_width(n, extra, xtri, c0, w, batch), info, batch, bs, is);
+    else if (leaf_on && g_panel_mode == 0 && batch >= rec_min_batch && w >= 128 && (w % 64 == 0) && (lda % 2 == 0) &&
+             g_potf2_exports_inv())
+        factor_panel_fused_split(s, A, lda, n, extra, xtri, c0, w, 128, info, batch, bs, is, true);
     else if (g_panel_mode == 3 || (g_panel_mode != 2 && batch < rec_min_batch))
         factor_panel_rl(s, A, lda, n, extra, xtri, c0, w, info, batch, bs, is);
     else

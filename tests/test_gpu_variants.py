@@ -41,13 +41,21 @@ ctx.svc_batch_set_pars(allp2)
 ctx.svc_batch_eval(hv, True, want_grad=True)
 bout2, status2 = ctx.svc_batch_fetch()
 bgrad2 = ctx.svc_batch_fetch_grad()
+# four chains, value + gradient: the smallest batch that takes the throughput schedule once NMGP_CHOL_FUSED_MAX_BATCH=0 rules out
+# the fused steps -- 128-column leaves (k_panel_step<1>, <2>) with the L^-T rows riding along
+ctx.svc_batch_alloc(4)
+allp4 = np.stack([sim.perturb(d2["pars_true"], 0.05, 0.2 + 0.1 * b) for b in range(4)])
+ctx.svc_batch_set_pars(allp4)
+ctx.svc_batch_eval(hv, True, want_grad=True)
+bout4, status4 = ctx.svc_batch_fetch()
+bgrad4 = ctx.svc_batch_fetch_grad()
 # a third subject with more than two 512-wide panels (n = 1200 = 512 + 512 + 176): the look-ahead schedule, its near update on
 # 64x64 tiles with the next panel's first block factored in the same launch, and a ragged last panel that takes neither
 d3 = sim.simulate_nonseparable(400, 3, seed=9)
 ctx.set_data(d3["x"], d3["Y"])
 out3, grad3 = ctx.logpos_svc(sim.perturb(d3["pars_true"], 0.05, 0.2), hv, prior=True, want_grad=True)
 print(json.dumps({"out3": list(map(float, out3)), "grad3": list(map(float, grad3)), "out": list(map(float, out)), "grad": list(map(float, grad)), "batch": bout.tolist(),
-                  "status": status.tolist() + status2.tolist(), "out2": list(map(float, out2)),
+                  "status": status.tolist() + status2.tolist() + status4.tolist(), "batch4": bout4.tolist(), "bgrad4": bgrad4.tolist(), "out2": list(map(float, out2)),
                   "grad2": list(map(float, grad2)), "batch2": bout2.tolist(), "bgrad2": bgrad2.tolist()}))
 """
 
@@ -63,7 +71,10 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "f"}, {"NMGP_POTF2": "valu"
             # fused steps under a recursive split (round 3), with the L^-T rows that enter panel by panel; substitution prior solves
             {"NMGP_CHOL_FUSED_BASE": "128"}, {"NMGP_CHOL_FUSED_BASE": "256", "NMGP_CHOL_PANEL": "fused"},
             {"NMGP_CHOL_FUSED_BASE": "128", "NMGP_CHOL_PANEL": "fused", "NMGP_POISON": "1"}, {"NMGP_PRIOR_SOLVE": "trsv"},
-            {"NMGP_SYRK_TRI_ORDER": "strips"}]
+            {"NMGP_SYRK_TRI_ORDER": "strips"},
+            # the throughput schedule on the snippet's small batches: leaf launches (default), with poisoned buffers, and the
+            # five-launch form they replace
+            {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_POISON": "1"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_CHOL_LEAF": "0"}]
 
 
 def run_variant(env_extra):
@@ -93,6 +104,8 @@ def test_kernel_variants_agree_with_the_default_configuration():
         assert vec_relerr(np.array(r["grad2"]), np.array(ref["grad2"])) < 1e-7, env_extra
         assert relerr(np.array(r["batch2"]), np.array(ref["batch2"])) < 1e-7, env_extra
         assert vec_relerr(np.array(r["bgrad2"]), np.array(ref["bgrad2"])) < 1e-7, env_extra
+        assert relerr(np.array(r["batch4"]), np.array(ref["batch4"])) < 1e-7, env_extra
+        assert vec_relerr(np.array(r["bgrad4"]), np.array(ref["bgrad4"])) < 1e-7, env_extra
         assert relerr(r["out3"][1], ref["out3"][1]) < 1e-11, (env_extra, r["out3"], ref["out3"])
         assert relerr(np.array(r["out3"]), np.array(ref["out3"])) < 1e-7, env_extra
         assert vec_relerr(np.array(r["grad3"]), np.array(ref["grad3"])) < 1e-7, env_extra

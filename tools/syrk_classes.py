@@ -7,8 +7,12 @@ Replays the factorisation's launch schedule (recursive-halving panels + trailing
 to the SYRK launches of the LAST evaluation in the trace, then prints time, TFLOP/s and algorithmic TB/s per class.
 """
 import csv
+import os
 import sys
 from collections import defaultdict
+
+
+LEAF = os.environ.get("NMGP_CHOL_LEAF", "1") != "0"
 
 
 def schedule(n, nb1, extra=1, xtri=0):
@@ -20,7 +24,9 @@ def schedule(n, nb1, extra=1, xtri=0):
         return n + extra + min(c1, xtri) - c1
 
     def rec(c0, w):
-        if w <= 64:
+        # (leaf: the library's default schedule ends the recursion at 128 columns -- k_panel_step<1>, <2> fold the K = 64
+        # update into the second solve; NMGP_CHOL_LEAF=0 in the environment of this tool restores the 64-column recursion)
+        if w <= 64 or (LEAF and w == 128):
             return
         h = ((w // 2 + 63) // 64) * 64
         if h >= w:
