@@ -714,6 +714,34 @@ def test_config5_separable_N4096_D5_both_formulations_against_reference_golden()
     assert vec_relerr(res["chol"][1], res["eig"][1]) < 1e-6
 
 
+@pytest.mark.parametrize("N,M,B", [(192, 3, 130), (213, 3, 120), (320, 2, 118), (256, 3, 100)])
+def test_throughput_schedule_leaves_match_single_evaluations(ctx, N, M, B):
+    """Batches with more than 73,728 rows in all take the throughput schedule, whose 128-column pieces are two leaf launches
+    (k_panel_step<1>, <2>: the K = 64 update folded into the second solve).  Value and gradient (the rows of L^-T enter the
+    leaves panel by panel) of such batches against single-chain evaluations, which take the fused 64-column steps: n = 576
+    (512 + a 64-column remainder), 639 (a last panel that is no multiple of 64: recursive fallback), 640 (512 + one leaf), 768."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    assert B * N * M > 73728
+    d = sim.simulate_nonseparable(N, M, seed=100 + N)
+    hv = [sim.HYPER_SVC[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")]
+    ctx.set_data(d["x"], d["Y"])
+    ctx.svc_batch_alloc(B)
+    pars = np.stack([sim.perturb(d["pars_true"], 0.05, 0.1 + 0.003 * k) for k in range(B)])
+    ctx.svc_batch_set_pars(pars)
+    ctx.svc_batch_eval(hv, True)
+    out, status = ctx.svc_batch_fetch()
+    assert np.all(status == 0) and np.all(np.isfinite(out))
+    ctx.svc_batch_eval(hv, True, want_grad=True)
+    outg, statusg = ctx.svc_batch_fetch()
+    grads = ctx.svc_batch_fetch_grad()
+    assert np.all(statusg == 0) and relerr(outg, out) < 1e-9
+    for k in (0, B // 3, B - 1):
+        single, gsingle = ctx.logpos_svc(pars[k], hv, prior=True, want_grad=True)
+        assert relerr(out[k][1], single[1]) < 1e-11 and relerr(out[k], single) < 1e-9, (k, out[k], single)
+        assert vec_relerr(grads[k], gsingle) < 1e-8, k
+    ctx.svc_batch_alloc(1)
+
+
 def test_headline_batch_of_128_chains_at_N2048(ctx):
     """The configuration bench.py times: 128 chains of the N = 2048, D = 3 subject in one launch sequence (2048-wide outer
     panels, recursive panel factorisation).  Chain 0 carries the golden parameters (reference value committed), three other
