@@ -1663,10 +1663,14 @@ void trsm_64(hipStream_t s, const double* L, int ldl, int nb, double* A, int lda
 //   MODE 1 = first step  (no previous block, a next one; no update role, no P waves): solve + the critical workgroup's D and its
 //            factorisation; 54 KB of LDS;
 //   MODE 2 = second step (a previous block, no next one): catch-up + solve; 52 KB of LDS.
-// With the flags known at compile time at most two 64-column row blocks are live per thread: 128 VGPRs, two workgroups per CU, so
-// that one's loads travel under the other's MFMAs and stores (the general step holds three blocks in 208 VGPRs, one per CU).
-template <int MODE>
-__global__ __launch_bounds__(512, MODE ? 4 : 2) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev_a,
+// With the flags known at compile time at most two 64-column row blocks are live per thread: 96 / 110 VGPRs (OCC = 4), two workgroups
+// per CU, so that one's loads travel under the other's MFMAs and stores (the general step holds three blocks in 191 VGPRs, one per
+// CU).  OCC = 6: three workgroups per CU (80 VGPRs, 3 x 53 KB of LDS) -- the second step gets there without spilling by issuing its
+// row loads only after its operands have gone to LDS (default for it: 128 chains +0.35 %, 64 subjects +0.8 %); the first step does
+// not (its critical workgroup's factorisation wants ~100 registers: 168 spilled, -1 % at 16 chains), it stays at 4.
+// NMGP_LEAF1_OCC / NMGP_LEAF2_OCC select.
+template <int MODE, int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void k_panel_step(double* __restrict__ Ab, int lda, int ck, int has_prev_a,
                                                         int has_next_a,
                                                         int m_act, int pend, long long bstride, int* __restrict__ info,
                                                         int istride, int T, int u_mrows, int u_ncols, int u_kflags,
@@ -1767,15 +1771,18 @@ __global__ __launch_bounds__(512, MODE ? 4 : 2) void k_panel_step(double* __rest
             ot[j] = v;
         }
     }
+    auto load_rows = [&]() {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * q + 4 * r + l4;
-            Tk[q][r] = rv ? A[(size_t)(ck + c) * lda + rowc] : 0.0;
-            Xp[q][r] = (rv && has_prev) ? Lp[(size_t)c * lda + rowc] : 0.0;
-            Un[q][r] = (rv && un_used && row < un_fresh) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * q + 4 * r + l4;
+                Tk[q][r] = rv ? A[(size_t)(ck + c) * lda + rowc] : 0.0;
+                Xp[q][r] = (rv && has_prev) ? Lp[(size_t)c * lda + rowc] : 0.0;
+                Un[q][r] = (rv && un_used && row < un_fresh) ? A[(size_t)(ck + 64 + c) * lda + rowc] : 0.0;
+            }
+    };
+    if constexpr (!(MODE == 2 && OCC == 6)) load_rows();
     // (2) operands to LDS
     if (has_prev) {
 #pragma unroll
@@ -1796,6 +1803,7 @@ __global__ __launch_bounds__(512, MODE ? 4 : 2) void k_panel_step(double* __rest
         const int blk = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
         smem[kOpsT + (blk * 64 + l) * 4 + kk] = ot[j];
     }
+    if constexpr (MODE == 2 && OCC == 6) load_rows();      // (the operand registers are free again: 80 VGPRs, three workgroups per CU)
     __syncthreads();
     PS_STAMP(1);
     // operands of the second catch-up (column block k + 1) travel while the first one computes (workgroup 0 takes them
@@ -2085,14 +2093,21 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         const int un_fresh = xtri > 0 ? n + extra + (has_prev ? ck - 64 : ck) : 0x7fffffff;
         const int u_tri = xtri > 0 ? n + extra - 192 : 0x7fffffff;
         if (leaf && pl.tiles == 0 && !pre && nk == 2) {
-            if (k == 0)
-                NMGP_LAUNCH(k_panel_step<1>, dim3((unsigned)(T * batch)), dim3(512), 0, s, A, lda, ck, 0, 1, m_act, c0 + w, bs, info, is, T,
-                            0, 0, 0, 0, batch, 0, un_fresh, u_tri, st);
-            else
-                NMGP_LAUNCH(k_panel_step<2>, dim3((unsigned)(T * batch)), dim3(512), 0, s, A, lda, ck, 1, 0, m_act, c0 + w, bs, info, is, T,
-                            0, 0, 0, 0, batch, 0, un_fresh, u_tri, st);
+            static const int occ1 = [] { const char* e = std::getenv("NMGP_LEAF1_OCC"); return e ? std::atoi(e) : 4; }();
+            static const int occ2 = [] { const char* e = std::getenv("NMGP_LEAF2_OCC"); return e ? std::atoi(e) : 6; }();
+#define NMGP_LEAF_LAUNCH(M, O, hp, hn)                                                                                          \
+    NMGP_LAUNCH((k_panel_step<M, O>), dim3((unsigned)(T * batch)), dim3(512), 0, s, A, lda, ck, hp, hn, m_act, c0 + w, bs, info, is, T, \
+                0, 0, 0, 0, batch, 0, un_fresh, u_tri, st)
+            if (k == 0) {
+                if (occ1 == 6) NMGP_LEAF_LAUNCH(1, 6, 0, 1);
+                else NMGP_LEAF_LAUNCH(1, 4, 0, 1);
+            } else {
+                if (occ2 == 6) NMGP_LEAF_LAUNCH(2, 6, 1, 0);
+                else NMGP_LEAF_LAUNCH(2, 4, 1, 0);
+            }
+#undef NMGP_LEAF_LAUNCH
         } else {
-            NMGP_LAUNCH(k_panel_step<0>, dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act,
+            NMGP_LAUNCH((k_panel_step<0, 2>), dim3((unsigned)((T + pl.tiles) * batch)), dim3(512), 0, s, A, lda, ck, has_prev, has_next, m_act,
                         c0 + w, bs, info, is, T, pl.mrows, u_n, pl.kflags, pl.tiles, batch, pre, un_fresh, u_tri, st);
         }
     }

@@ -74,7 +74,9 @@ VARIANTS = [{}, {"NMGP_TRSM": "valu"}, {"NMGP_TRSM": "f"}, {"NMGP_POTF2": "valu"
             {"NMGP_SYRK_TRI_ORDER": "strips"},
             # the throughput schedule on the snippet's small batches: leaf launches (default), with poisoned buffers, and the
             # five-launch form they replace
-            {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_POISON": "1"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_CHOL_LEAF": "0"}]
+            {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_POISON": "1"}, {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_CHOL_LEAF": "0"},
+            # ... and the other register budgets of the two leaf kernels (defaults: first step 4 waves per SIMD, second step 6)
+            {"NMGP_CHOL_FUSED_MAX_BATCH": "0", "NMGP_LEAF1_OCC": "6", "NMGP_LEAF2_OCC": "4"}]
 
 
 def run_variant(env_extra):
