@@ -61,3 +61,31 @@ def test_bench_prints_one_valid_json_line(extra):
         assert "grad" not in rec and "gradients" in rec["config"]["host_reads_per_step"]
     assert rl["traffic"] is None and rl["traffic_note"]          # no PMC measurement exists for this toy size
     assert np.isfinite(rec["value"]) and rec["value"] > 0
+
+
+def test_profile_tools_replay_the_launch_schedule_of_the_throughput_path():
+    """tools/syrk_classes.py attaches (rows, columns, K) to the k_syrk_lower launches of a trace by replaying the host
+    schedule: recursive halving of 2048-wide outer panels down to the 128-column leaves (two k_panel_step launches, no
+    update launch) -- or down to 64 columns when NMGP_CHOL_LEAF=0.  Flop of the replayed launches + the leaves' K = 64 share
+    must add up to the factorisation's update flop."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import syrk_classes
+    n, nb1 = 6144, 2048
+    old = syrk_classes.LEAF
+    try:
+        syrk_classes.LEAF = True
+        leaf = syrk_classes.schedule(n, nb1)
+        syrk_classes.LEAF = False
+        full = syrk_classes.schedule(n, nb1)
+    finally:
+        syrk_classes.LEAF = old
+    assert len(leaf) == 47 and len(full) == 95           # the launch counts in profiles/r03_batched128_last_eval.txt / r02
+    assert sorted(set(k for _, _, k in full)) == [64, 128, 256, 512, 1024, 2048]
+    assert sorted(set(k for _, _, k in leaf)) == [128, 256, 512, 1024, 2048]
+    assert [t for t in full if t[2] != 64] == leaf       # the leaves only remove the K = 64 launches
+
+    def flop(sched):
+        return sum(2.0 * k * (nc * m - 0.5 * nc * (nc - 1)) for m, nc, k in sched)
+    # all update launches together: n^3/3 minus the diagonal blocks and panel solves (98.5 % at n = 6144, one extra row)
+    assert 0.98 < flop(full) / (n ** 3 / 3.0) < 0.99
+    assert 0.96 < flop(leaf) / (n ** 3 / 3.0) < flop(full) / (n ** 3 / 3.0)
