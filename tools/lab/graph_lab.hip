@@ -53,6 +53,22 @@ static void lookahead(hipStream_t s1, hipStream_t s2, hipEvent_t* ev, const Patt
     CK(hipStreamWaitEvent(s1, ev[2 * p.panels - 1], 0));
 }
 
+// pattern B without the second stream (what the launches alone cost), and with the events but an empty far update
+static void lookahead_variant(hipStream_t s1, hipStream_t s2, hipEvent_t* ev, const Pattern& p, int* sink, int variant) {
+    for (int k = 0; k < p.panels; ++k) {
+        for (int i = 0; i < p.steps; ++i) spin(s1, 200, p.step_us, sink);
+        if (variant >= 1 && k > 0) CK(hipStreamWaitEvent(s1, ev[2 * k - 1], 0));
+        spin(s1, 600, p.near_us, sink);
+        if (variant >= 1) {
+            CK(hipEventRecord(ev[2 * k], s1));
+            CK(hipStreamWaitEvent(s2, ev[2 * k], 0));
+            spin(s2, variant == 1 ? 1 : 192, variant == 1 ? 0.5 : p.far_us, sink);
+            CK(hipEventRecord(ev[2 * k + 1], s2));
+        }
+    }
+    if (variant >= 1) CK(hipStreamWaitEvent(s1, ev[2 * p.panels - 1], 0));
+}
+
 template <class F>
 static double time_ms(hipStream_t s1, int reps, F&& f) {
     CK(hipStreamSynchronize(s1));
@@ -104,5 +120,13 @@ int main() {
                 "stream between two events (critical path %.3f ms)\n", p.panels, p.steps, p.step_us, p.near_us, p.far_us, busy_b);
     std::printf("  stream launches %.3f ms  (+%.2f us per panel)\n", b_stream, (b_stream - busy_b) * 1e3 / p.panels);
     std::printf("  one graph       %.3f ms  (+%.2f us per panel)\n", b_graph, (b_graph - busy_b) * 1e3 / p.panels);
+    for (int v = 0; v < 3; ++v) {
+        lookahead_variant(s1, s2, ev, p, sink, v);
+        const double t = time_ms(s1, reps, [&] { lookahead_variant(s1, s2, ev, p, sink, v); });
+        std::printf("  %-58s %.3f ms  (+%.2f us per panel)\n",
+                    v == 0 ? "main stream alone (no second stream, no events)"
+                           : (v == 1 ? "events + a 0.5 us one-workgroup kernel on the second stream" : "as pattern B (again)"),
+                    t, (t - busy_b) * 1e3 / p.panels);
+    }
     return 0;
 }
