@@ -53,16 +53,27 @@ static void lookahead(hipStream_t s1, hipStream_t s2, hipEvent_t* ev, const Patt
     CK(hipStreamWaitEvent(s1, ev[2 * p.panels - 1], 0));
 }
 
+static unsigned int *g_flag = nullptr, *g_flag2 = nullptr;     // signal memory for the stream-memory-operation variants
+static unsigned int g_seq = 0;
+
 // pattern B without the second stream (what the launches alone cost), and with the events but an empty far update
 static void lookahead_variant(hipStream_t s1, hipStream_t s2, hipEvent_t* ev, const Pattern& p, int* sink, int variant) {
     for (int k = 0; k < p.panels; ++k) {
         for (int i = 0; i < p.steps; ++i) spin(s1, 200, p.step_us, sink);
-        if (variant >= 1 && k > 0) CK(hipStreamWaitEvent(s1, ev[2 * k - 1], 0));
+        if (variant == 5 && k > 0) CK(hipStreamWaitValue32(s1, g_flag2, g_seq, hipStreamWaitValueGte, 0xffffffffu));
+        else if (variant >= 1 && variant != 3 && k > 0) CK(hipStreamWaitEvent(s1, ev[2 * k - 1], 0));
         spin(s1, 600, p.near_us, sink);
-        if (variant >= 1) {
+        if (variant == 4 || variant == 5) {          // main -> second stream through a value in memory instead of an event
+            ++g_seq;
+            CK(hipStreamWriteValue32(s1, g_flag, g_seq, 0));
+            CK(hipStreamWaitValue32(s2, g_flag, g_seq, hipStreamWaitValueGte, 0xffffffffu));
+            spin(s2, 1, 0.5, sink);
+            if (variant == 5) CK(hipStreamWriteValue32(s2, g_flag2, g_seq, 0));      // ... and back the same way
+            CK(hipEventRecord(ev[2 * k + 1], s2));
+        } else if (variant >= 1) {
             CK(hipEventRecord(ev[2 * k], s1));
             CK(hipStreamWaitEvent(s2, ev[2 * k], 0));
-            spin(s2, variant == 1 ? 1 : 192, variant == 1 ? 0.5 : p.far_us, sink);
+            spin(s2, variant == 2 ? 192 : 1, variant == 2 ? p.far_us : 0.5, sink);
             CK(hipEventRecord(ev[2 * k + 1], s2));
         }
     }
@@ -120,12 +131,20 @@ int main() {
                 "stream between two events (critical path %.3f ms)\n", p.panels, p.steps, p.step_us, p.near_us, p.far_us, busy_b);
     std::printf("  stream launches %.3f ms  (+%.2f us per panel)\n", b_stream, (b_stream - busy_b) * 1e3 / p.panels);
     std::printf("  one graph       %.3f ms  (+%.2f us per panel)\n", b_graph, (b_graph - busy_b) * 1e3 / p.panels);
-    for (int v = 0; v < 3; ++v) {
+    CK(hipExtMallocWithFlags((void**)&g_flag, 8, hipMallocSignalMemory));
+    CK(hipMemset(g_flag, 0, 8));
+    CK(hipExtMallocWithFlags((void**)&g_flag2, 8, hipMallocSignalMemory));
+    CK(hipMemset(g_flag2, 0, 8));
+    for (int v = 0; v < 6; ++v) {
         lookahead_variant(s1, s2, ev, p, sink, v);
         const double t = time_ms(s1, reps, [&] { lookahead_variant(s1, s2, ev, p, sink, v); });
         std::printf("  %-58s %.3f ms  (+%.2f us per panel)\n",
                     v == 0 ? "main stream alone (no second stream, no events)"
-                           : (v == 1 ? "events + a 0.5 us one-workgroup kernel on the second stream" : "as pattern B (again)"),
+                           : (v == 1 ? "events + a 0.5 us one-workgroup kernel on the second stream"
+                                     : (v == 2 ? "as pattern B (again)"
+                                                : (v == 3 ? "as the second line, main stream never waits for the second"
+                                                          : (v == 4 ? "as the second line, main -> second through hipStreamWriteValue32 / WaitValue32"
+                                                                    : "... and second -> main through memory values as well")))),
                     t, (t - busy_b) * 1e3 / p.panels);
     }
     return 0;
