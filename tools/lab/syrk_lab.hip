@@ -204,6 +204,15 @@ __global__ __launch_bounds__(512, 4) void k_syrk_fast(const double* __restrict__
     constexpr int BK = 16;
     __shared__ double sA[2][BK * SY_LD];
     __shared__ double sB[2][BK * SY_LD];
+    // V & 64/128: de-phase the two workgroups that share a CU -- the second 256 workgroups of the launch (the second resident of every
+    // CU, if the dispatcher deals the first 512 round-robin) start half a tile (64) / a quarter (128) late; later workgroups inherit
+    // the slot, and the phase, of the one they replace
+    if ((V & 192) && blockIdx.x >= 256 && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
+        const long long ticks = (V & 64) ? (long long)K * 5 / 2 : (long long)K * 5 / 4;      // 100 MHz: K = 512 -> 12.8 / 6.4 us
+        const long long t0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - t0 < ticks) {
+        }
+    }
     int bi = blockIdx.x, bj = blockIdx.y, bz = blockIdx.z;
     if (swz && !decode_tile(swz, nbatch, mrows, ncols, bi, bj, bz)) return;
     if (bi < bj) return;
@@ -438,6 +447,9 @@ int main(int argc, char** argv) {
     run("w8_nomask_nopre_sched", [&] { hipLaunchKernelGGL((k_syrk<4, 16, 35>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("w4_nomask_sched", [&] { hipLaunchKernelGGL((k_syrk<2, 16, 33>), gs, dim3(256), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast", [&] { hipLaunchKernelGGL((k_syrk_fast<0>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
+    run("fast_dephase_half", [&] { hipLaunchKernelGGL((k_syrk_fast<64>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
+    run("fast_dephase_quarter", [&] { hipLaunchKernelGGL((k_syrk_fast<128>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
+    run("fast_again", [&] { hipLaunchKernelGGL((k_syrk_fast<0>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_samepanel", [&] { hipLaunchKernelGGL((k_syrk_fast<32>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_midstore", [&] { hipLaunchKernelGGL((k_syrk_fast<2>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
     run("fast_midstore_sched", [&] { hipLaunchKernelGGL((k_syrk_fast<3>), gs, dim3(512), 0, s, A, ld, C, ld, m - 1, nc, K, bs, bs, tiles_of((m - 1 + 127) / 128, gy), batch); });
