@@ -52,24 +52,27 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def measured_traffic(N, M, chains, want_grad=False, workload="chain"):
-    """HBM bytes of the k_syrk_lower launches of one step, as measured by the rocprofv3 PMC passes whose summary is
-    committed under profiles/ (FETCH_SIZE x2 for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md).  The figure belongs to the
-    kernel source it was measured on: profiles/traffic.json stores the SHA-256 of csrc/nmgp_chol.hip next to it and the
-    figure is reported only while that file is unchanged -- otherwise null, with the reason."""
+    """HBM bytes of one step as measured by the rocprofv3 PMC passes whose summary is committed under profiles/ (FETCH_SIZE x2
+    for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md) -> (bytes, note, scope).  `scope` names the kernels the figure covers
+    ("k_syrk_lower launches" for the value line, whose roofline names that kernel; "every kernel of the evaluation" for the
+    end-to-end rooflines) and goes into the JSON as `traffic_scope`.  The figure belongs to the kernel source it was
+    measured on: profiles/traffic.json stores the SHA-256 of csrc/nmgp_chol.hip next to it and the figure is reported only
+    while that file is unchanged -- otherwise null, with the reason."""
     try:
         with open(TRAFFIC_FILE) as f:
             entries = json.load(f)["entries"]
         with open(CHOL_SOURCE, "rb") as f:
             sha = hashlib.sha256(f.read()).hexdigest()
     except Exception as e:      # noqa: BLE001
-        return None, "no committed PMC measurement (%s)" % type(e).__name__
+        return None, "no committed PMC measurement (%s)" % type(e).__name__, None
     for e in entries:
         if (e["N"], e["M"], e["chains"], bool(e.get("grad", False)), e.get("workload", "chain")) == (
                 N, M, chains, bool(want_grad), workload):
             if e["chol_sha256"] != sha:
-                return None, "stale: %s was measured on another revision of csrc/nmgp_chol.hip" % e["source"]
-            return float(e["bytes_per_step"]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % e["source"]
-    return None, "no committed PMC measurement for N=%d, M=%d, %d %s%s" % (N, M, chains, workload, ", value+gradient" if want_grad else "")
+                return None, "stale: %s was measured on another revision of csrc/nmgp_chol.hip" % e["source"], e.get("scope")
+            return float(e["bytes_per_step"]), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s" % e["source"], e.get("scope")
+    return None, "no committed PMC measurement for N=%d, M=%d, %d %s%s" % (
+        N, M, chains, workload, ", value+gradient" if want_grad else ""), None
 
 
 # ---- product backend: libnmgp_hip.so on one MI355X per rank, RCCL between ranks -------------------------------------
@@ -98,6 +101,19 @@ class HipBackend:
 
     def sync(self):
         self.torch.cuda.synchronize()
+
+    def identity(self):
+        """Which GPU this rank really drives: torch's current device, its PCI address and UUID, and the device the HIP
+        library itself reports as current (both must be LOCAL_RANK) -- first-contact evidence for a multi-GPU run."""
+        t = self.torch
+        pr = t.cuda.get_device_properties(self.local_rank)
+        pci = None
+        if hasattr(pr, "pci_bus_id"):
+            pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+        from nonstationary_multivariate_gaussian_process_amd import _lib
+        return {"local_rank": self.local_rank, "torch_current_device": int(t.cuda.current_device()), "name": pr.name,
+                "pci_bus_id": pci, "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid(),
+                "visible_devices": int(t.cuda.device_count()), "library_build_id": _lib.build_id()}
 
     def chains(self, d, allp, hv, groups):
         return HipChains(self.local_rank, d, allp, hv, groups)
@@ -226,9 +242,26 @@ def per_rank(value, world, device):
     return [float(o[0]) for o in out]
 
 
+RANK_IDS = None          # every rank's identity() in rank order, gathered once after the process group is up
+
+
+def gather_identities(be, rank, world):
+    """All ranks: collect {rank, local_rank, device, PCI address, pid, ...} of every rank (one all-gather of small objects)."""
+    ident = getattr(be, "identity", None)
+    mine = dict(ident() if ident else {"local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}, rank=rank)
+    if not _dist_on(world):
+        return [mine]
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
 def dist_report(be, world, rank_seconds, steps):
-    """What the process group looked like from rank 0, and the spread of the ranks' own step times (the headline uses the max)."""
-    rep = {"world_size_env": world, "ms_per_step_by_rank": [1e3 * t / max(steps, 1) for t in rank_seconds],
+    """What the process group looked like from rank 0, every rank's device, and the spread of the ranks' own step times (the
+    headline uses the max)."""
+    rep = {"world_size_env": world, "self_launched": os.environ.get("NMGP_BENCH_SELF_LAUNCHED") == "1",
+           "ms_per_step_by_rank": [1e3 * t / max(steps, 1) for t in rank_seconds],
            "ms_per_step_min_rank": 1e3 * min(rank_seconds) / max(steps, 1),
            "ms_per_step_max_rank": 1e3 * max(rank_seconds) / max(steps, 1)}
     dc = getattr(be, "device_count", None)
@@ -236,6 +269,10 @@ def dist_report(be, world, rank_seconds, steps):
     if _dist_on(world):
         import torch.distributed as dist
         rep["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
+    if RANK_IDS is not None:
+        rep["ranks"] = RANK_IDS
+        pcis = [r.get("pci_bus_id") for r in RANK_IDS if r.get("pci_bus_id")]
+        rep["distinct_gpus"] = len(set(pcis)) if pcis else None      # must equal the world size on a real multi-GPU run
     return rep
 
 
@@ -321,7 +358,7 @@ def run_chains(a, rank, world, be):
         g_rate = a.grad_steps * world * B / g_elapsed
         g_tf = g_rate * float(n) ** 3 / 1e12 / world
         gnorm = float(np.linalg.norm(ev.grads[0])) if ev.grads is not None else None
-        g_traffic, g_traffic_note = measured_traffic(N, M, B, True) if prof is not None else (None, "no HIP backend")
+        g_traffic, g_traffic_note, g_scope = measured_traffic(N, M, B, True) if prof is not None else (None, "no HIP backend", None)
         grad_rec = {"what": "nlogpos_obj_SVC value + gradient of every chain per step (gradients copied to the host "
                             "every step), same %d chain(s) per GPU" % B,
                     "value": g_rate, "unit": "evals/s", "steps": a.grad_steps, "ms_per_step": 1e3 * g_elapsed / a.grad_steps,
@@ -329,7 +366,7 @@ def run_chains(a, rank, world, be):
                     "roofline": {"what": "end to end: n^3 flop per value+gradient evaluation (SURVEY 8d W_fb) x evals/s "
                                          "per GPU", "bound": "mfma", "achieved": g_tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS,
-                                 "traffic": g_traffic, "traffic_note": g_traffic_note},
+                                 "traffic": g_traffic, "traffic_note": g_traffic_note, "traffic_scope": g_scope},
                     "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in g_stage.items() if v[1] > 0}}
     # end-to-end MCMC rate: BatchedHMC (drivers.py) advances B chains in lock-step, 20 leapfrog steps per sample, step size 1e-4
     # (Nonseparable_model.py:228-231), every step one batched value+gradient launch sequence + the leapfrog kernels.  Like the
@@ -444,7 +481,7 @@ def hip_chain_report(a, ctx, stage, kprof, B, n, want_grad):
         hbm = ctx.measure_hbm_rates(1 << 30, 10)
     except Exception:       # noqa: BLE001 -- measurement helpers are informative only
         dgemm_tf, hbm = None, {"copy": None, "read": None, "write": None}
-    traffic, traffic_note = measured_traffic(N, M, B, want_grad)
+    traffic, traffic_note, traffic_scope = measured_traffic(N, M, B, want_grad)
     return {
         "config_extra": {"stage_ms": stage_ms, "measured_dgemm_tflops_n4096": dgemm_tf, "measured_hbm_copy_gbs": hbm["copy"],
                          "measured_hbm_read_gbs": hbm["read"], "measured_hbm_write_gbs": hbm["write"],
@@ -457,6 +494,7 @@ def hip_chain_report(a, ctx, stage, kprof, B, n, want_grad):
                                "elements) / sum of HIP-event launch durations on the launching stream" % (B0, n, n),
                      "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                     "traffic_scope": traffic_scope,
                      "syrk": syrk_info,
                      "factorisation": {"what": "whole CHOL stage (syrk + potf2 + trsm + row moves), chains*n^3/3 flop%s "
                                                "over the HIP-event stage time of the timed region" % (
@@ -503,7 +541,7 @@ def run_subjects(a, rank, world, be):
         chol_s = stage_ms.get("chol", 0.0) * 1e-3
         fact_tf = (len(mine) * K * (2.0 if want_grad else 1.0) * float(n) ** 3 / 3.0) / chol_s / 1e12 if chol_s > 0 else 0.0
         total = a.steps * n_subj * K
-        traffic, traffic_note = measured_traffic(N, M, len(mine) * K, want_grad, "subjects")
+        traffic, traffic_note, traffic_scope = measured_traffic(N, M, len(mine) * K, want_grad, "subjects")
         rec = {
             "metric": "log-posterior evals/sec (%d subjects, N=%d, D=%d nonseparable GP)" % (n_subj, N, M),
             "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -520,13 +558,73 @@ def run_subjects(a, rank, world, be):
                                    "kernels%s): subjects * n^3/3 flop%s over the HIP-event stage time" % (
                                        ", with the L^-T rows" if want_grad else "", " x 2" if want_grad else ""),
                          "bound": "mfma", "achieved": fact_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fact_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note},
+                         "frac": fact_tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_scope": traffic_scope},
             "distributed": dist_report(be, world, rank_seconds, a.steps)}
         if world > 1:
             rec["cpu_baseline_note"] = ("absent on purpose: the CPU oracle is timed by rank 0 of single-GPU runs only (N=1); the "
                                         "single-GPU chain workload's line carries it")
     ev.close()
     return rec, stats, table
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(argv, n, script=None, out=None, timeout=None):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: THIS process -- which has imported
+    neither torch nor the HIP library and has made no HIP call, and never will -- starts the N ranks as a CHILD
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same
+    arguments>` (one rank per GPU over RCCL; a process that has touched the GPU is never re-exec'ed, a child is spawned
+    and its exit code returned), relays rank 0's single JSON line to stdout and everything else the ranks print to
+    stderr, and returns non-zero if any rank failed or the line count is not exactly one.  The reference's launch
+    line for the same pattern is `mpirun -n 40 python Nonseparable_model_mpisim.py` (sim_job:9).
+    `script` lets tests/test_bench_selflaunch.py point the ranks at a wrapper that calls bench.main with the gloo
+    backend; bench.py itself always launches itself."""
+    import subprocess
+    out = out if out is not None else sys.stdout
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["NMGP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    print("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as a child process: %s" % (n, " ".join(cmd)),
+          file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    lines = []
+    try:
+        for ln in p.stdout:
+            is_rec = False
+            if ln.startswith("{"):
+                try:
+                    is_rec = "metric" in json.loads(ln)
+                except ValueError:
+                    is_rec = False
+            if is_rec:
+                lines.append(ln)
+            else:
+                sys.stderr.write(ln)
+        rc = p.wait(timeout=timeout)
+    except BaseException:
+        p.kill()            # the exact child we started; torch.distributed.run takes its workers down with it
+        p.wait()
+        raise
+    if rc != 0:
+        print("bench.py: the torch.distributed.run child exited with %d (a rank failed)" % rc, file=sys.stderr, flush=True)
+        return rc
+    if len(lines) != 1:
+        print("bench.py: expected exactly one JSON line from rank 0, got %d" % len(lines), file=sys.stderr, flush=True)
+        return 1
+    out.write(lines[0])
+    out.flush()
+    return 0
 
 
 def parse_args(argv=None):
@@ -576,8 +674,12 @@ def main(argv=None, backend=None):
     program always builds the HIP backend and fails loudly without a GPU."""
     a = parse_args(argv)
     rank, world, local_rank = dist_env()
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus %d needs a torch.distributed launch (WORLD_SIZE=%d)" % (a.gpus, world))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and backend is None:
+        # before anything touches HIP / torch.cuda: become the launcher of the N ranks (see self_launch)
+        raise SystemExit(self_launch(sys.argv[1:] if argv is None else argv, a.gpus))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (`python bench.py --gpus N` does it by itself, "
+                         "or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)" % (a.gpus, world))
     be = backend if backend is not None else HipBackend(local_rank)
     global DIST_ACTIVE
     if world > 1 or a.dist_selftest:
@@ -589,11 +691,15 @@ def main(argv=None, backend=None):
             os.environ.setdefault("MASTER_PORT", "29511")
         be.init_dist(rank, world)
         DIST_ACTIVE = True
+    global RANK_IDS
+    RANK_IDS = gather_identities(be, rank, world)
     rec, stats, table = (run_subjects if a.workload == "subjects" else run_chains)(a, rank, world, be)
     if rank == 0:
         extra = rec.pop("config_extra", None)
         if extra:
             rec["config"].update(extra)
+        if RANK_IDS and RANK_IDS[0].get("library_build_id"):
+            rec["config"]["library_build_id"] = RANK_IDS[0]["library_build_id"]      # == build.tree_id() of the sources (_lib.load checks)
         print(json.dumps(rec), flush=True)
     if DIST_ACTIVE:
         import torch.distributed as dist

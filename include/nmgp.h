@@ -55,6 +55,9 @@ int nmgp_ctx_create(int device, nmgp_ctx** out);
 int nmgp_ctx_destroy(nmgp_ctx* ctx);
 const char* nmgp_last_error(const nmgp_ctx* ctx);
 int nmgp_version(void);
+/* SHA-256 (hex) of the sources, headers and code-generation flags the library was built from (build.py: tree_id()).
+ * The Python binding refuses a shared object whose id differs from the source tree beside it. */
+const char* nmgp_build_id(void);
 /* Blocks until all work queued on the context's stream is complete. */
 int nmgp_sync(nmgp_ctx* ctx);
 /* Number of visible HIP devices (does not create a context). */

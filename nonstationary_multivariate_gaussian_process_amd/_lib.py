@@ -30,6 +30,7 @@ SIGNATURES = {
     "nmgp_ctx_destroy": (I, [V]),
     "nmgp_last_error": (ctypes.c_char_p, [V]),
     "nmgp_version": (I, []),
+    "nmgp_build_id": (ctypes.c_char_p, []),
     "nmgp_sync": (I, [V]),
     "nmgp_device_count": (I, []),
     "nmgp_set_data": (I, [V, P, P, I, I]),
@@ -116,10 +117,21 @@ def load(require_gpu=True):
                 fn = getattr(lib, name)        # AttributeError if the .so does not export it
                 fn.restype = res
                 fn.argtypes = args
+            # provenance: the shared object must be the build of THIS tree (sources + headers + flags), not a stale one
+            from . import build as _build
+            have, want = lib.nmgp_build_id().decode(), _build.tree_id()
+            if have != want:
+                raise NmgpError("libnmgp_hip.so is stale: it was built from tree %s..., the sources beside it hash to %s... "
+                                "Rebuild with `python -m nonstationary_multivariate_gaussian_process_amd.build`." % (have[:16], want[:16]))
             _lib = lib
     if require_gpu and _lib.nmgp_device_count() <= 0:
         raise NmgpError("no HIP device is visible: the MI355X path cannot run (and there is no CPU fallback)")
     return _lib
+
+
+def build_id():
+    """The loaded library's build id (== build.tree_id() of the tree, or load() would have refused it)."""
+    return load(require_gpu=False).nmgp_build_id().decode()
 
 
 def as_f64(a):

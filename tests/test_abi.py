@@ -35,6 +35,27 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.nmgp_version() == 100
 
 
+def test_loaded_library_is_the_build_of_this_tree(tmp_path, monkeypatch):
+    """Build provenance: nmgp_build_id() == SHA-256 of the sources + headers + flags beside the shared object; a change of
+    any source without a rebuild makes _lib.load() refuse the library instead of running stale kernels."""
+    from nonstationary_multivariate_gaussian_process_amd import build as b, _lib
+    b.build(verbose=False)
+    tid = b.tree_id()
+    assert len(tid) == 64 and _lib.build_id() == tid
+    # the id covers every source, both headers and the flags
+    for extra_flag in (["-O2"],):
+        monkeypatch.setattr(b, "CODEGEN_FLAGS", b.CODEGEN_FLAGS + extra_flag)
+        assert b.tree_id() != tid
+        monkeypatch.undo()
+    # a stale library is refused: pretend the tree moved on
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(b, "tree_id", lambda: "0" * 64)
+    with pytest.raises(_lib.NmgpError, match="stale"):
+        _lib.load(require_gpu=False)
+    monkeypatch.undo()
+    assert _lib.load(require_gpu=False).nmgp_build_id().decode() == tid
+
+
 def test_no_gpu_means_loud_failure():
     from nonstationary_multivariate_gaussian_process_amd import _lib
     lib = _lib.load(require_gpu=False)

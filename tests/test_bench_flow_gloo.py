@@ -188,7 +188,8 @@ def test_measured_traffic_lookup_is_keyed_by_workload_and_pinned_to_the_kernel_s
     doc = {"entries": [
         {"N": 2048, "M": 3, "chains": 128, "grad": False, "workload": "chain", "bytes_per_step": 1.0, "source": "a", "chol_sha256": sha},
         {"N": 2048, "M": 3, "chains": 128, "grad": True, "workload": "chain", "bytes_per_step": 2.0, "source": "b", "chol_sha256": sha},
-        {"N": 1024, "M": 3, "chains": 8, "grad": False, "workload": "subjects", "bytes_per_step": 3.0, "source": "c", "chol_sha256": sha},
+        {"N": 1024, "M": 3, "chains": 8, "grad": False, "workload": "subjects", "bytes_per_step": 3.0, "source": "c", "chol_sha256": sha,
+         "scope": "every kernel of the evaluation"},
         {"N": 1024, "M": 3, "chains": 64, "grad": False, "workload": "subjects", "bytes_per_step": 4.0, "source": "d",
          "chol_sha256": "0" * 64}]}
     f = tmp_path / "traffic.json"
@@ -197,9 +198,10 @@ def test_measured_traffic_lookup_is_keyed_by_workload_and_pinned_to_the_kernel_s
     assert bench.measured_traffic(2048, 3, 128)[0] == 1.0
     assert bench.measured_traffic(2048, 3, 128, True)[0] == 2.0
     assert bench.measured_traffic(1024, 3, 8, False, "subjects")[0] == 3.0
-    v, why = bench.measured_traffic(1024, 3, 8, False, "chain")
+    assert bench.measured_traffic(1024, 3, 8, False, "subjects")[2] == "every kernel of the evaluation"      # -> roofline.traffic_scope
+    v, why, _ = bench.measured_traffic(1024, 3, 8, False, "chain")
     assert v is None and "no committed PMC measurement" in why
-    v, why = bench.measured_traffic(1024, 3, 64, False, "subjects")
+    v, why, scope = bench.measured_traffic(1024, 3, 64, False, "subjects")
     assert v is None and "stale" in why
     # the committed file itself: entries for the headline, its value+gradient step and config 4's per-GPU shape
     monkeypatch.undo()
