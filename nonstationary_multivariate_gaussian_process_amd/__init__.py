@@ -31,4 +31,25 @@ def install_utility_alias(reference_utility_dir=None):
         sys.modules["Utility." + name] = getattr(Utility, name)
     if reference_utility_dir is not None:
         _overlay.attach(reference_utility_dir)
+    install_hmc_sampler()
     return Utility
+
+
+def install_hmc_sampler(force=False):
+    """Make ``import HMC_Sampler`` work for the scripts' sampler line (Nonseparable_model.py:24-25,228-231).  The reference's
+    sampler package is external to its repository; ours (``HMC_Sampler/HMC_sampler.py`` -> ``drivers.HMCSampler``) is registered
+    under the top-level name ONLY when the user has no ``HMC_Sampler`` of their own on ``sys.path`` (or with ``force``).
+    Returns the module that ``import HMC_Sampler`` will yield, or None when the user's own package is left in charge."""
+    import importlib.util
+    if not force:
+        if "HMC_Sampler" in sys.modules:
+            return sys.modules["HMC_Sampler"]
+        try:
+            if importlib.util.find_spec("HMC_Sampler") is not None:
+                return None
+        except (ImportError, ValueError):
+            pass
+    from . import HMC_Sampler as pkg
+    sys.modules["HMC_Sampler"] = pkg
+    sys.modules["HMC_Sampler.HMC_sampler"] = pkg.HMC_sampler
+    return pkg

@@ -2223,6 +2223,13 @@ struct HookScope {
 
 void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int lda, int n, int extra, int xtri,
                  int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook, int precise) {
+    if (xtri > 0 && trtri_post_applies(n, xtri, lda, batch)) {
+        // the rows of L^-T do not ride through the factorisation: value-form factorisation (the `extra` dense rows only), then
+        // the blocked triangular inversion of nmgp_trtri.hip writes X = L^-T where the riding rows would have ended up
+        potrf_lower(s, s2, ev, A, lda, n, extra, 0, nb1, info, batch, bstride, istride, hook, precise);
+        trtri_upper_post(s, A, lda, n, n + extra, batch, bstride, hook);
+        return;
+    }
     HookScope hs(hook);
     struct StampScope {          // allocate before, dump after the factorisation (synchronises: developer aid only)
         hipStream_t s;

@@ -369,4 +369,8 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
                  int nb1, int* info, int batch, long long bstride, int istride, const SyrkHook* hook = nullptr,
                  int precise = 0);
 
+// ---- nmgp_trtri.hip ----
+bool trtri_post_applies(int n, int xtri, int lda, int batch);
+void trtri_upper_post(hipStream_t s, double* S, int ld, int n, int xoff, int batch, long long bs, const SyrkHook* hook);
+
 }  // namespace nmgpk

@@ -184,6 +184,45 @@ def test_hmc_energy_conservation_on_the_nonseparable_potential(tmp_path):
 
 
 @pytest.mark.gpu
+def test_the_scripts_sampler_line_runs_unchanged_on_the_shipped_hmc_sampler():
+    """Nonseparable_model.py:24-25,228-231 as written: `import HMC_Sampler` (the authors' external package, absent from the
+    reference tree) resolves to the mirror's HMC_Sampler package once the alias is installed, and the script's sampler call --
+    same keywords, incl. TensorType -- returns (samples [sample_size, P], _)."""
+    import sys
+    import nonstationary_multivariate_gaussian_process_amd as nmgp_amd
+    saved = {k: sys.modules.get(k) for k in ("HMC_Sampler", "HMC_Sampler.HMC_sampler")}
+    try:
+        nmgp_amd.install_utility_alias()
+        nmgp_amd.install_hmc_sampler(force=True)
+        import HMC_Sampler
+        from Utility import logpos
+        from Utility import settings
+        g = golden("svc_rngfree_N32_M2")
+        hyper_pars = hyper_dict(g["hyper"], SVC_KEYS)
+        x, Y = torch.from_numpy(g["x"]).type(settings.torchType), torch.from_numpy(g["Y"]).type(settings.torchType)
+        estPars, N_hmc = g["pars"], 5
+        hmc = HMC_Sampler.HMC_sampler.sampler(sample_size=N_hmc, potential_func=logpos.nlogpos_obj_SVC, init_position=estPars,
+                                              step_size=1e-4, num_steps_in_leap=20, x=x, Y=Y, duplicate_samples=True, TensorType=settings.torchType,
+                                              **hyper_pars)
+        sample, _ = hmc.main_hmc_loop()
+        assert sample.shape == (N_hmc, estPars.shape[0]) and np.all(np.isfinite(sample))
+        assert np.linalg.norm(sample[-1] - estPars) > 0          # it moved
+        # the production call of the MPI variants (Nonseparable_model_mpiKAISER.py:267-270): mass matrix + adaptive step size
+        P = estPars.shape[0]
+        hmc2 = HMC_Sampler.HMC_sampler.sampler(sample_size=3, potential_func=logpos.nlogpos_obj_SVC, init_position=torch.from_numpy(estPars),
+                                               step_size=1e-4, adaptive_step_size=True, num_steps_in_leap=5, M=np.eye(P), x=x, Y=Y,
+                                               duplicate_samples=True, TensorType=settings.torchType, **hyper_pars)
+        s2, info2 = hmc2.main_hmc_loop()
+        assert s2.shape == (3, P) and info2["step_size"] > 0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+@pytest.mark.gpu
 def test_batched_hmc_chains_follow_the_single_chain_sampler():
     """Lock-step batched chains (one launch sequence per leapfrog step for all chains) reproduce the trajectories of
     the single-chain sampler started from the same state with the same random stream."""

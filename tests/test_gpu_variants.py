@@ -157,3 +157,59 @@ def test_bench_dist_selftest_runs_rccl_next_to_the_library_streams():
     assert rec["distributed"]["process_group"] == {"backend": "nccl", "world_size": 1, "rank": 0}
     assert rec["config"]["chains_ok"] == 3 and rec["config"]["chain_table_rows"] == 3 and rec["value"] > 0
     assert rec["grad"]["chains_ok"] == 3
+
+
+TRTRI_SNIPPET = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+from oracle import nmgp_oracle as O          # checker
+hv = [sim.HYPER_SVC[k] for k in ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")]
+res = {}
+ctx = _lib.Context(0)
+for (N, M, B) in ((128, 2, 3), (128, 3, 1), (256, 3, 5), (512, 3, 2)):       # n = 256, 384, 768, 1536: 2, 3, 6, 12 leaf blocks
+    d = sim.simulate_nonseparable(N, M, seed=11 + N + M)
+    ctx.set_data(d["x"], d["Y"])
+    p0 = sim.perturb(d["pars_true"], 0.05, 0.2)
+    out, grad = ctx.logpos_svc(p0, hv, prior=True, want_grad=True)
+    ref, gref = O.nlogpos_obj_SVC(p0, d["Y"], d["x"], **sim.HYPER_SVC, verbose=True, grad=True)
+    key = "N%%d_M%%d" %% (N, M)
+    res[key] = {"out": list(map(float, out)), "grad": list(map(float, grad)),
+                "oracle_rel": float(abs(out[0] - ref[0]) / abs(ref[0])),
+                "oracle_grad_rel": float(np.linalg.norm(grad - gref) / np.linalg.norm(gref))}
+    if B > 1:
+        ctx.svc_batch_alloc(B)
+        allp = np.stack([sim.perturb(d["pars_true"], 0.05, 0.2 + 0.1 * b) for b in range(B)])
+        ctx.svc_batch_set_pars(allp)
+        ctx.svc_batch_eval(hv, True, want_grad=True)
+        bout, status = ctx.svc_batch_fetch()
+        res[key].update(batch=bout.tolist(), bgrad=ctx.svc_batch_fetch_grad().tolist(), status=status.tolist())
+print(json.dumps(res))
+"""
+
+
+def test_blocked_triangular_inversion_agrees_with_the_riding_rows_and_the_oracle():
+    """Gradient evaluations whose n is a multiple of 128 build X = L^-T AFTER the factorisation (nmgp_trtri.hip: leaf blocks by
+    substitution, then products with explicit inverses of the diagonal blocks); NMGP_TRTRI=0 keeps the round-3 form (identity rows
+    riding through the factorisation).  Both must give the same objective and gradient -- sizes with 2, 3, 6 and 12 leaf blocks, i.e.
+    power-of-two levels only, the left-to-right top combine only, and both --, with NaN-poisoned buffers too, and match the oracle."""
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", TRTRI_SNIPPET % {"root": ROOT}], capture_output=True, text=True, timeout=900,
+                             env=env, cwd=ROOT)
+        assert out.returncode == 0, (env_extra, out.stderr[-2000:])
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    ref = run({"NMGP_TRTRI": "0"})
+    for env_extra in ({}, {"NMGP_TRTRI": "1", "NMGP_POISON": "1"}, {"NMGP_TRTRI": "1", "NMGP_CHOL_FUSED_MAX_BATCH": "0"}):
+        r = run(env_extra)
+        for key, a in r.items():
+            b = ref[key]
+            assert a["oracle_rel"] < 1e-6 and a["oracle_grad_rel"] < 1e-5, (env_extra, key, a["oracle_rel"], a["oracle_grad_rel"])
+            assert relerr(a["out"][1], b["out"][1]) < 1e-11, (env_extra, key)
+            assert vec_relerr(np.array(a["grad"]), np.array(b["grad"])) < 1e-7, (env_extra, key)
+            if "batch" in a:
+                assert all(s == 0 for s in a["status"])
+                assert relerr(np.array(a["batch"]), np.array(b["batch"])) < 1e-7, (env_extra, key)
+                assert vec_relerr(np.array(a["bgrad"]), np.array(b["bgrad"])) < 1e-7, (env_extra, key)

@@ -22,8 +22,8 @@ pytestmark = pytest.mark.skipif(not os.path.isfile(SCRIPT), reason="reference ch
 CHILD = textwrap.dedent('''
     import os, sys, types
     sys.dont_write_bytecode = True
-    # stand-ins for what the image lacks: the external HMC package (absent from the reference tree) and seaborn
-    sys.modules["HMC_Sampler"] = types.ModuleType("HMC_Sampler")
+    # stand-in for what the image lacks: seaborn.  (The external HMC package of line 25 -- absent from the reference tree -- is
+    # served by the mirror's own HMC_Sampler package: no stub.)
     sys.modules["seaborn"] = types.ModuleType("seaborn")
     MODE = sys.argv[1]
     if MODE == "alias":
@@ -41,6 +41,15 @@ CHILD = textwrap.dedent('''
     assert "from Utility import logpos" in block and "empirical_estimation" in block
     exec(compile(block, {script!r}, "exec"))
     mirror = os.path.join({root!r}, "nonstationary_multivariate_gaussian_process_amd", "Utility")
+    # line 25 `import HMC_Sampler` got the mirror's sampler package, with the entry point the script calls at lines 228-231
+    import inspect as _insp
+    assert os.path.dirname(os.path.abspath(_insp.getsourcefile(HMC_Sampler.HMC_sampler.sampler))) == os.path.join(
+        {root!r}, "nonstationary_multivariate_gaussian_process_amd", "HMC_Sampler"), HMC_Sampler
+    _sig = _insp.signature(HMC_Sampler.HMC_sampler.sampler.__init__).parameters
+    for _k in ("sample_size", "potential_func", "init_position", "step_size", "num_steps_in_leap", "duplicate_samples", "TensorType",
+               "M", "adaptive_step_size"):
+        assert _k in _sig, _k
+    assert callable(HMC_Sampler.HMC_sampler.sampler.main_hmc_loop)
     def where(obj):
         import inspect
         return os.path.dirname(os.path.abspath(inspect.getsourcefile(obj)))
@@ -130,7 +139,7 @@ def test_utility_imports_of_every_reference_script_resolve_on_the_overlay():
     code = textwrap.dedent('''
         import os, sys, types, re
         sys.dont_write_bytecode = True
-        for name in ("HMC_Sampler", "seaborn", "mpi4py", "pyGPs", "statsmodels", "gpytorch"):
+        for name in ("seaborn", "mpi4py", "pyGPs", "statsmodels", "gpytorch"):
             sys.modules.setdefault(name, types.ModuleType(name))
         sys.path.append("..")              # what every one of these scripts does before its imports
         sys.path.insert(0, %r)
@@ -161,3 +170,33 @@ def test_utility_imports_of_every_reference_script_resolve_on_the_overlay():
     r = subprocess.run([sys.executable, "-c", code] + scripts, cwd=os.path.join(REF, "Nonseparable_Model"), env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "IMPORTS-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_users_own_hmc_sampler_package_wins(tmp_path):
+    """The mirror's HMC_Sampler is a stand-in for a package the user normally HAS (the authors' sibling checkout, line 24 of the
+    script appends its directory to sys.path): when one is importable, install_utility_alias() leaves it in charge, and reached
+    through PYTHONPATH the mirror's package hands over to it."""
+    own = tmp_path / "Hamiltonian_Monte_Carlo" / "HMC_Sampler"
+    own.mkdir(parents=True)
+    (own / "__init__.py").write_text("MINE = True\nfrom . import HMC_sampler\n")
+    (own / "HMC_sampler.py").write_text("class sampler:\n    pass\n")
+    code = textwrap.dedent('''
+        import sys
+        sys.path.append(%r)                  # what line 24 of the script does
+        MODE = sys.argv[1]
+        if MODE == "alias":
+            sys.path.insert(0, %r)
+            import nonstationary_multivariate_gaussian_process_amd as nmgp_amd
+            nmgp_amd.install_utility_alias()
+        import HMC_Sampler
+        assert getattr(HMC_Sampler, "MINE", False) is True, HMC_Sampler
+        assert HMC_Sampler.HMC_sampler.sampler.__module__ == "HMC_Sampler.HMC_sampler"
+        print("OWN-OK", MODE)
+    ''') % (str(tmp_path / "Hamiltonian_Monte_Carlo"), ROOT)
+    for mode in ("alias", "pythonpath"):
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        env.pop("PYTHONPATH", None)
+        if mode == "pythonpath":
+            env["PYTHONPATH"] = os.path.join(ROOT, "nonstationary_multivariate_gaussian_process_amd")
+        r = subprocess.run([sys.executable, "-c", code, mode], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "OWN-OK" in r.stdout, r.stdout + r.stderr
