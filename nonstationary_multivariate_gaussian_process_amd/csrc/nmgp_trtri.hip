@@ -1,6 +1,8 @@
 // Blocked triangular inversion X = L^-T AFTER the factorisation (gradient evaluations; DESIGN.md "value+gradient step").
 //
-// Until round 3 the n rows of X rode below the matrix through EVERY level of the factorisation's panel recursion (identity rows
+// SELECTABLE ALTERNATIVE (NMGP_TRTRI=1), not the default: measured equal to the riding rows at 128 chains and slower for small
+// batches -- figures at trtri_post_applies() below.
+// By default the n rows of X ride below the matrix through EVERY level of the factorisation's panel recursion (identity rows
 // that the panel solves and updates turn into L^-T): the HBM-bound K <= 512 update classes and the leaf launches then work on
 // twice the rows (72 of 288 ms of a 128-chain step).  Here the factorisation runs in its value form (the right-hand side row
 // only) and X is built afterwards from products with EXPLICIT inverses of the diagonal blocks, so that all but ~2 % of the
@@ -309,9 +311,12 @@ __global__ __launch_bounds__(256) void k_trtri_leaf128(double* __restrict__ S, i
 static void tri_gemm_pair(hipStream_t s, double* S, int ld, long long bs, int batch, int xoff, int a0, int a1, int a2, int npairs,
                           long long pstride, const SyrkHook* hook) {
     const int m1 = a1 - a0, m2 = a2 - a1;
-    static const int order_env = [] {          // NMGP_TRTRI_ORDER=rows: equal-length tiles consecutive, no XCD grouping (A/B)
+    // NMGP_TRTRI_ORDER=lockstep: the XCD-lockstep tile order (L2 reuse of the operand panels) instead of equal-length tiles
+    // consecutive.  Measured, 128 chains: factorisation + inversion 312.9 ms (rows) against 315.3-316.8 (lockstep) -- at 4.3 TB/s of
+    // operand traffic through the fabric these launches are still not bound by it
+    static const int order_env = [] {
         const char* e = std::getenv("NMGP_TRTRI_ORDER");
-        return (e && std::strcmp(e, "rows") == 0) ? 0 : 1;
+        return (e && std::strcmp(e, "lockstep") == 0) ? 1 : 0;
     }();
     const int t1 = m1 / 128, t2 = m2 / 128;
     const int lock = (order_env && ((long long)npairs * batch) % 8 == 0 && (t1 < 8 || t1 % 8 == 0) && (t2 < 8 || t2 % 8 == 0)) ? 1 : 0;
@@ -339,20 +344,23 @@ static void tri_gemm_pair(hipStream_t s, double* S, int ld, long long bs, int ba
 }
 
 // Whether potrf_lower builds the n rows of L^-T after the factorisation (this file) instead of letting them ride through it.
-// NMGP_TRTRI=0 restores the riding rows; =1 forces the blocked inversion wherever it is defined.
+// NMGP_TRTRI=1 selects the blocked inversion wherever it is defined (n a multiple of 128); the DEFAULT is the riding rows.
+// Measured on MI355X (round 4, same box, alternating runs; evals/s value+gradient, riding rows -> blocked inversion): 128 chains
+// of n = 6144 267.4 -> 266.9 (factorisation + inversion 312.9 -> 312.9 ms: the inversion takes 159 ms -- leaf 1.9, levels 128 /
+// 256 / 512 / 1024 0.6 / 1.3 / 4.4 / 14.9, the two top combines 34.8 + 101.4 -- for n^3/3 flop per matrix = 62 TFLOP/s, 67-68
+// on the flop its tiles execute, exactly what the riding rows cost); 32 / 16 chains 265.9 -> 261.7 / 256.7 -> 250.8; 4 chains
+// 214.8 -> 222.1; one chain 168.2 -> 141.2; 8 subjects x N = 1024 1335 -> 1188; 64 subjects 1766 -> 1717; separable N = 4096,
+// D = 5 9.09 -> 9.42 ms.  The K <= 512 classes the riding rows double are paid back one for one by the inversion's short levels
+// and by the zero halves of its diagonal tiles.
 bool trtri_post_applies(int n, int xtri, int lda, int batch) {
     static const int mode = [] {
         const char* e = std::getenv("NMGP_TRTRI");
-        return e ? std::atoi(e) : -1;
-    }();
-    if (mode == 0 || xtri != n || n < 256 || (n % 128) != 0 || (lda & 1)) return false;
-    if ((long long)(n + 16) * lda * 8 >= 0x7fff0000LL) return false;      // 32-bit byte offsets into a k-panel
-    if (mode == 1) return true;
-    static const int min_rows = [] {
-        const char* e = std::getenv("NMGP_TRTRI_MIN_ROWS");
         return e ? std::atoi(e) : 0;
     }();
-    return (long long)batch * n >= min_rows;
+    (void)batch;
+    if (mode != 1 || xtri != n || n < 256 || (n % 128) != 0 || (lda & 1)) return false;
+    if ((long long)(n + 16) * lda * 8 >= 0x7fff0000LL) return false;      // 32-bit byte offsets into a k-panel
+    return true;
 }
 
 // X = L^-T into rows xoff .. xoff + n - 1 of the factorisation buffer (see the header of this file).  L must be complete.

@@ -190,8 +190,8 @@ print(json.dumps(res))
 
 
 def test_blocked_triangular_inversion_agrees_with_the_riding_rows_and_the_oracle():
-    """Gradient evaluations whose n is a multiple of 128 build X = L^-T AFTER the factorisation (nmgp_trtri.hip: leaf blocks by
-    substitution, then products with explicit inverses of the diagonal blocks); NMGP_TRTRI=0 keeps the round-3 form (identity rows
+    """NMGP_TRTRI=1: gradient evaluations whose n is a multiple of 128 build X = L^-T AFTER the factorisation (nmgp_trtri.hip: leaf
+    blocks by substitution, then products with explicit inverses of the diagonal blocks) instead of the default (identity rows
     riding through the factorisation).  Both must give the same objective and gradient -- sizes with 2, 3, 6 and 12 leaf blocks, i.e.
     power-of-two levels only, the left-to-right top combine only, and both --, with NaN-poisoned buffers too, and match the oracle."""
     def run(env_extra):
@@ -202,7 +202,8 @@ def test_blocked_triangular_inversion_agrees_with_the_riding_rows_and_the_oracle
         assert out.returncode == 0, (env_extra, out.stderr[-2000:])
         return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     ref = run({"NMGP_TRTRI": "0"})
-    for env_extra in ({}, {"NMGP_TRTRI": "1", "NMGP_POISON": "1"}, {"NMGP_TRTRI": "1", "NMGP_CHOL_FUSED_MAX_BATCH": "0"}):
+    for env_extra in ({"NMGP_TRTRI": "1"}, {"NMGP_TRTRI": "1", "NMGP_POISON": "1"}, {"NMGP_TRTRI": "1", "NMGP_CHOL_FUSED_MAX_BATCH": "0"},
+                      {"NMGP_TRTRI": "1", "NMGP_TRTRI_ORDER": "lockstep"}):
         r = run(env_extra)
         for key, a in r.items():
             b = ref[key]
