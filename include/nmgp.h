@@ -123,11 +123,23 @@ double* nmgp_svc_batch_grad_dev(nmgp_ctx* ctx);
  *                               M = inv(sample covariance), step size 1e-1, 5 leapfrog steps): kind 0 identity (default),
  *                               1 diagonal (minv = diag(M^-1) [P]), 2 dense (minv = M^-1 [P,P], row-major == column-major: it is
  *                               symmetric).  The drift becomes q += eps M^-1 p (dense: one GEMM per leapfrog step for all chains);
- *                               momenta p ~ N(0, M) and the kinetic energy 1/2 p^T M^-1 p remain the caller's. */
+ *                               with nmgp_svc_batch_traj the momenta p ~ N(0, M) and the kinetic energy 1/2 p^T M^-1 p remain
+ *                               the caller's.  Changing the metric (or the batch's subjects) invalidates a begun trajectory.
+ *   nmgp_svc_batch_traj_set_mass_chol: a square root of M for the same kind -- sqrt(diag M) [P], or R [P,P] COLUMN-major with
+ *                               R R^T = M (the lower Cholesky factor, zeros stored above the diagonal, or any other) -- so that
+ *                               the device can draw the momenta itself
+ *   nmgp_svc_batch_traj_z     : like nmgp_svc_batch_traj, but z [B,P] in are STANDARD NORMALS: p0 = chol(M) z is formed on the
+ *                               device (start kinetic energy = 1/2 |z|^2 for any metric) and kin1 [B] = 1/2 p1^T M^-1 p1 comes
+ *                               back instead of p1 -- no [B,P] x [P,P] product is left on the host.
+ * An API-level failure in the middle of a trajectory (either entry) restores the start state and requires a fresh value+gradient
+ * evaluation + nmgp_svc_batch_traj_begin. */
 int nmgp_svc_batch_traj_begin(nmgp_ctx* ctx);
 int nmgp_svc_batch_traj_set_mass(nmgp_ctx* ctx, int kind, const double* minv);
+int nmgp_svc_batch_traj_set_mass_chol(nmgp_ctx* ctx, int kind, const double* mchol);
 int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
                         double* q1, double* p1, double* U1, int* failed);
+int nmgp_svc_batch_traj_z(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* z,
+                          double* q1, double* kin1, double* U1, int* failed);
 int nmgp_svc_batch_traj_commit(nmgp_ctx* ctx, const int* accept);
 
 /* Device-resident Adam over the batch -- the MAP loop of Nonseparable_model.py:147-210 (torch.optim.Adam, default betas / eps)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "nmgp_svc_batch_traj_begin": (I, [V]),
     "nmgp_svc_batch_traj_set_mass": (I, [V, I, P]),
     "nmgp_svc_batch_traj": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_traj_set_mass_chol": (I, [V, I, P]),
+    "nmgp_svc_batch_traj_z": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_adam_begin": (I, [V]),
     "nmgp_svc_batch_adam_step": (I, [V, P, I, D, D, D, D, P, ctypes.POINTER(ctypes.c_int)]),
@@ -289,6 +291,35 @@ class Context:
         else:
             raise ValueError("minv must be [P] or [P, P] with P = %d" % P)
         self.check(self.lib.nmgp_svc_batch_traj_set_mass(self.h, kind, ptr(minv)))
+
+    def svc_batch_traj_set_mass_chol(self, mchol):
+        """chol(M) of the mass matrix set by svc_batch_traj_set_mass: sqrt(diag M) [P] or a square root R [P, P] with R R^T = M
+        (NumPy row-major; np.linalg.cholesky(M), or e.g. L^-T when M^-1 = L L^T is what one has) -- lets svc_batch_traj_z draw
+        the momenta p = R z on the device."""
+        mchol = as_f64(mchol)
+        P = self.N * (1 + self.T) + 1
+        if mchol.shape == (P,):
+            self.check(self.lib.nmgp_svc_batch_traj_set_mass_chol(self.h, 1, ptr(mchol)))
+        elif mchol.shape == (P, P):
+            mt = np.ascontiguousarray(mchol.T)                   # column-major R == row-major of its transpose
+            self.check(self.lib.nmgp_svc_batch_traj_set_mass_chol(self.h, 2, ptr(mt)))
+        else:
+            raise ValueError("mchol must be [P] or [P, P] with P = %d" % P)
+
+    def svc_batch_traj_z(self, hyper, prior, eps, nsteps, z):
+        """One leapfrog trajectory per chain with momenta p0 = chol(M) z formed on the device from the standard normals z [B, P]:
+        returns the end point q1 [B, P], the kinetic energy there kin1 [B] = 1/2 p1^T M^-1 p1, the potential U1 [B] (inf for failed
+        chains) and failed [B] (bool)."""
+        hyper, z = as_f64(hyper), as_f64(z)
+        P_ = self.N * (1 + self.T) + 1
+        if z.shape != (self.B, P_):
+            raise NmgpError("z must be [B=%d, P=%d], got %s" % (self.B, P_, z.shape))
+        q1, kin1, U1 = np.empty((self.B, P_)), np.empty(self.B), np.empty(self.B)
+        failed = np.zeros(self.B, dtype=np.int32)
+        self.check(self.lib.nmgp_svc_batch_traj_z(self.h, ptr(hyper), int(bool(prior)), float(eps), int(nsteps), ptr(z),
+                                                  ptr(q1), ptr(kin1), ptr(U1),
+                                                  failed.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return q1, kin1, U1, failed.astype(bool)
 
     def svc_batch_traj(self, hyper, prior, eps, nsteps, p0):
         """One leapfrog trajectory per chain from the resident state with momenta p0 [B, P]: returns the end point

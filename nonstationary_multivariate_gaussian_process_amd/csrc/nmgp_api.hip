@@ -652,7 +652,7 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
-                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel};
+                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel, &c->b_mchol, &c->b_kin};
     c->b_mass_kind = 0;
     c->b_cps = 1;
     if (c->b_alive) hipFree(c->b_alive);
@@ -751,6 +751,9 @@ extern "C" int nmgp_svc_batch_set_subjects_chains(nmgp_ctx* c, const double* x, 
     c->b_priors.clear();
     c->b_multi = true;
     c->b_cps = chains_per_subject;
+    // new data: the resident gradient and a trajectory begun on the old subjects no longer describe the batch
+    c->b_traj_ready = false;
+    c->b_last_grad = false;
     return 0;
 }
 
@@ -1047,8 +1050,10 @@ extern "C" int nmgp_svc_batch_traj_set_mass(nmgp_ctx* c, int kind, const double*
     const size_t P = (size_t)c->P_svc, B = c->batch;
     if (c->b_minv) hipFree(c->b_minv);
     if (c->b_vel) hipFree(c->b_vel);
-    c->b_minv = c->b_vel = nullptr;
+    if (c->b_mchol) hipFree(c->b_mchol);
+    c->b_minv = c->b_vel = c->b_mchol = nullptr;
     c->b_mass_kind = 0;
+    c->b_traj_ready = false;             // a trajectory begun under the old metric must be begun again
     if (kind == 0) return 0;
     const size_t nelem = kind == 1 ? P : P * P;
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_minv, nelem));
@@ -1056,6 +1061,26 @@ extern "C" int nmgp_svc_batch_traj_set_mass(nmgp_ctx* c, int kind, const double*
     HIP_TRY(c, hipMemcpyAsync(c->b_minv, minv, nelem * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->b_mass_kind = kind;
+    return 0;
+}
+
+// A square root of the mass matrix set by nmgp_svc_batch_traj_set_mass (same kind): diagonal: sqrt(diag M) [P]; dense: R with
+// R R^T = M, COLUMN-major [P, P] (element (i, j) at mchol[i + j P]; e.g. the lower Cholesky factor with zeros above the diagonal).  With it
+// nmgp_svc_batch_traj_z draws the momenta on the device: p = chol(M) z from the standard normals z the caller uploads.
+extern "C" int nmgp_svc_batch_traj_set_mass_chol(nmgp_ctx* c, int kind, const double* mchol) {
+    if (!c) return NMGP_E_NULL;
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    if (kind != c->b_mass_kind) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_set_mass(kind = %d) must come first (current kind %d)", kind, c->b_mass_kind);
+    if (kind == 0) return 0;
+    if (!mchol) return nmgp_fail(c, NMGP_E_NULL, "mchol must not be NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t P = (size_t)c->P_svc;
+    const size_t nelem = kind == 1 ? P : P * P;
+    if (c->b_mchol) hipFree(c->b_mchol);
+    c->b_mchol = nullptr;
+    NMGP_TRY(nmgp_dev_alloc(c, &c->b_mchol, nelem));
+    HIP_TRY(c, hipMemcpyAsync(c->b_mchol, mchol, nelem * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1083,6 +1108,44 @@ static int traj_kick_drift(nmgp_ctx* c, double kick, double eps, int drift) {
     return 0;
 }
 
+// The leapfrog loop shared by nmgp_svc_batch_traj / nmgp_svc_batch_traj_z: the momenta are in b_mom.  ANY API-level failure in
+// the middle of a trajectory (an evaluation, a library GEMM of the dense-mass drift -- not a chain's numerical failure: those
+// are flags) goes through ONE block that puts the start state back and demands a fresh value+gradient evaluation before the next
+// nmgp_svc_batch_traj_begin, so that a caller who retries cannot continue from a half-advanced position.
+static int traj_run(nmgp_ctx* c, const double hyper[8], int prior, double eps, int nsteps) {
+    const int B = c->batch;
+    const long long P = c->P_svc;
+    const size_t bytes = (size_t)B * P * sizeof(double);
+    hipStream_t s = c->stream;
+    int* bad = c->b_hmc;
+    int* bad0 = c->b_hmc + B;
+    int* fl = c->b_hmc + 2 * B;
+    HIP_TRY(c, hipMemcpyAsync(c->b_q0, c->b_pars, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->b_g0, c->b_grad, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(bad0, bad, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(fl, 0, (size_t)B * sizeof(int), s));
+    int rc = traj_kick_drift(c, 0.5 * eps, eps, 1);
+    for (int step = 0; rc == 0 && step < nsteps; ++step) {
+        rc = nmgp_svc_batch_eval(c, hyper, prior, 1);
+        if (rc) break;
+        hmc_status(s, c->b_info, c->b_scal, bad, fl, B);
+        const bool last = step == nsteps - 1;
+        rc = traj_kick_drift(c, last ? 0.5 * eps : eps, eps, last ? 0 : 1);
+    }
+    if (rc) {
+        const std::string msg = c->err;                  // keep the first failure's message
+        hipMemcpyAsync(c->b_pars, c->b_q0, bytes, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(c->b_grad, c->b_g0, bytes, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(bad, bad0, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s);
+        hipStreamSynchronize(s);
+        c->b_last_grad = false;
+        c->b_traj_ready = false;
+        c->err = msg;
+        return rc;
+    }
+    return 0;
+}
+
 // One trajectory for every chain: p0 [B, P] (host) are the momenta drawn by the caller; `nsteps` leapfrog steps of size `eps`
 // (mass matrix: nmgp_svc_batch_traj_set_mass, identity by default), one batched value+gradient evaluation per step.  Returns the end point q1, p1 [B, P], the
 // potential there U1 [B] and failed [B] = 1 for a chain whose potential was undefined at ANY point of the trajectory (to be
@@ -1098,40 +1161,65 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
     const long long P = c->P_svc;
     const size_t bytes = (size_t)B * P * sizeof(double);
     hipStream_t s = c->stream;
-    int* bad = c->b_hmc;
-    int* bad0 = c->b_hmc + B;
-    int* fl = c->b_hmc + 2 * B;
     HIP_TRY(c, hipMemcpyAsync(c->b_mom, p0, bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->b_q0, c->b_pars, bytes, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->b_g0, c->b_grad, bytes, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(bad0, bad, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(fl, 0, (size_t)B * sizeof(int), s));
-    NMGP_TRY(traj_kick_drift(c, 0.5 * eps, eps, 1));
-    for (int step = 0; step < nsteps; ++step) {
-        if (int rc = nmgp_svc_batch_eval(c, hyper, prior, 1)) {
-            // an API-level failure in the middle of a trajectory (not a chain's numerical failure: those are flags): put the
-            // start state back and demand a fresh value+gradient evaluation before the next nmgp_svc_batch_traj_begin, so
-            // that a caller who retries cannot continue from a half-advanced position
-            hipMemcpyAsync(c->b_pars, c->b_q0, bytes, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(c->b_grad, c->b_g0, bytes, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(bad, bad0, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s);
-            hipStreamSynchronize(s);
-            c->b_last_grad = false;
-            c->b_traj_ready = false;
-            return rc;
-        }
-        hmc_status(s, c->b_info, c->b_scal, bad, fl, B);
-        const bool last = step == nsteps - 1;
-        NMGP_TRY(traj_kick_drift(c, last ? 0.5 * eps : eps, eps, last ? 0 : 1));
-    }
+    NMGP_TRY(traj_run(c, hyper, prior, eps, nsteps));
     std::vector<double> h((size_t)B * 16);
     HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(p1, c->b_mom, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(failed, fl, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     NMGP_TRY(nmgp_take_launch_error(c));
     for (int z = 0; z < B; ++z) U1[z] = failed[z] ? INFINITY : h[(size_t)z * 16 + 8];
+    c->b_traj_ready = true;
+    return 0;
+}
+
+// The same trajectory with the momenta DRAWN ON THE DEVICE: z [B, P] (host) are standard normals, p0 = chol(M) z (identity: p0 = z;
+// diagonal / dense: nmgp_svc_batch_traj_set_mass_chol must have uploaded chol(M) -- one GEMM [P, P] x [P, B] for all chains), so the
+// start kinetic energy is 1/2 |z|^2 whatever the metric, and the END kinetic energy kin1 [B] = 1/2 p1^T M^-1 p1 comes back
+// instead of the momenta themselves (dense: one more GEMM; a reduction per chain).  This is what makes a dense-mass sample cost
+// what an identity-mass one does: the host's share was two [B, P] x [P, P] products per sample in NumPy (P = 14,337).
+extern "C" int nmgp_svc_batch_traj_z(nmgp_ctx* c, const double hyper[8], int prior, double eps, int nsteps, const double* z,
+                                     double* q1, double* kin1, double* U1, int* failed) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper || !z || !q1 || !kin1 || !U1 || !failed) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
+    if (!c->b_traj_ready) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_begin must be called on the current state");
+    if (nsteps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "nsteps must be positive");
+    if (c->b_mass_kind != 0 && !c->b_mchol)
+        return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_set_mass_chol must upload chol(M) before momenta can be drawn on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int B = c->batch;
+    const long long P = c->P_svc;
+    const size_t bytes = (size_t)B * P * sizeof(double);
+    hipStream_t s = c->stream;
+    const double one = 1.0, zero = 0.0;
+    if (!c->b_kin) NMGP_TRY(nmgp_dev_alloc(c, &c->b_kin, (size_t)B));
+    if (c->b_mass_kind == 2) {
+        // p0 [P x B] = chol(M) [P x P] z [P x B]   (z staged in the velocity buffer)
+        HIP_TRY(c, hipMemcpyAsync(c->b_vel, z, bytes, hipMemcpyHostToDevice, s));
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (int)P, B, (int)P, &one, c->b_mchol,
+                                  (int)P, c->b_vel, (int)P, &zero, c->b_mom, (int)P));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->b_mom, z, bytes, hipMemcpyHostToDevice, s));
+        if (c->b_mass_kind == 1) hmc_scale(s, c->b_mom, c->b_mchol, P, B);
+    }
+    NMGP_TRY(traj_run(c, hyper, prior, eps, nsteps));
+    if (c->b_mass_kind == 2) {
+        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (int)P, B, (int)P, &one, c->b_minv,
+                                  (int)P, c->b_mom, (int)P, &zero, c->b_vel, (int)P));
+        hmc_kinetic(s, c->b_mom, c->b_vel, nullptr, c->b_kin, P, B);
+    } else {
+        hmc_kinetic(s, c->b_mom, nullptr, c->b_mass_kind == 1 ? c->b_minv : nullptr, c->b_kin, P, B);
+    }
+    std::vector<double> h((size_t)B * 16);
+    HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(kin1, c->b_kin, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    NMGP_TRY(nmgp_take_launch_error(c));
+    for (int k = 0; k < B; ++k) U1[k] = failed[k] ? INFINITY : h[(size_t)k * 16 + 8];
     c->b_traj_ready = true;
     return 0;
 }

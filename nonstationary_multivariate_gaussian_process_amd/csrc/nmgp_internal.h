@@ -143,6 +143,8 @@ struct nmgp_ctx {
     int b_mass_kind = 0;        // mass matrix of the device-resident trajectories: 0 identity, 1 diagonal, 2 dense (b_minv = M^-1)
     double* b_minv = nullptr;   // [P] or [P, P]
     double* b_vel = nullptr;    // [B, P] velocities M^-1 p (dense mass matrix)
+    double* b_mchol = nullptr;  // chol(M): [P] (diagonal: sqrt) or [P, P] lower, column-major -- momenta p = chol(M) z drawn on the device
+    double* b_kin = nullptr;    // [B] kinetic energies 1/2 p^T M^-1 p at the end of a trajectory
     int last_sep_attempts = 0;  // jitter retries the last separable / stationary evaluation needed (0 = the exact covariance)
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
@@ -289,6 +291,8 @@ void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, in
 void hmc_kick_drift(hipStream_t s, double* p, const double* g, double* q, const int* bad, double c, double eps, int drift,
                     long long P, int B);
 void hmc_drift(hipStream_t s, double* q, const double* p, const double* vel, const double* minv_diag, double eps, long long P, int B);
+void hmc_scale(hipStream_t s, double* p, const double* d, long long P, int B);
+void hmc_kinetic(hipStream_t s, const double* p, const double* vel, const double* minv_diag, double* kin, long long P, int B);
 void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
                  const int* accept, long long P, int B);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,

@@ -480,6 +480,44 @@ __global__ __launch_bounds__(256) void k_hmc_restore(double* __restrict__ q, dou
     g[o] = g0[o];
 }
 
+// p[z, i] = mchol_diag[i] * p[z, i]: momenta p = chol(M) z of a DIAGONAL mass matrix from the standard normals the caller uploaded
+__global__ __launch_bounds__(256) void k_hmc_scale(double* __restrict__ p, const double* __restrict__ d, long long P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t o = (size_t)blockIdx.y * P + i;
+    p[o] = d[i] * p[o];
+}
+
+// kin[z] = 1/2 sum_i p[z, i] v[z, i], v = M^-1 p: p itself (identity), minv_diag[i] p (diagonal) or `vel` (dense: the caller's GEMM).
+// One workgroup per chain, fixed summation order (strided partial sums, then a tree): the same bits on every call.
+__global__ __launch_bounds__(256) void k_hmc_kinetic(const double* __restrict__ p, const double* __restrict__ vel,
+                                                      const double* __restrict__ minv_diag, double* __restrict__ kin, long long P) {
+    __shared__ double red[256];
+    const int z = blockIdx.x, t = threadIdx.x;
+    const double* pz = p + (size_t)z * P;
+    const double* vz = vel ? vel + (size_t)z * P : nullptr;
+    double acc = 0.0;
+    for (long long i = t; i < P; i += 256) {
+        const double pv = pz[i];
+        const double v = vz ? vz[i] : (minv_diag ? minv_diag[i] * pv : pv);
+        acc = fma(pv, v, acc);
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h) red[t] += red[t + h];
+        __syncthreads();
+    }
+    if (t == 0) kin[z] = 0.5 * red[0];
+}
+
+void hmc_scale(hipStream_t s, double* p, const double* d, long long P, int B) {
+    NMGP_LAUNCH(k_hmc_scale, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, s, p, d, P);
+}
+void hmc_kinetic(hipStream_t s, const double* p, const double* vel, const double* minv_diag, double* kin, long long P, int B) {
+    NMGP_LAUNCH(k_hmc_kinetic, dim3(B), dim3(256), 0, s, p, vel, minv_diag, kin, P);
+}
+
 void hmc_status(hipStream_t s, const int* info, const double* scal, int* bad, int* failed, int B) {
     NMGP_LAUNCH(k_hmc_status, dim3(cdiv(B, 64)), dim3(64), 0, s, info, scal, bad, failed, B);
 }

@@ -442,10 +442,15 @@ class BatchedHMC(LockStepHMC):
     """
 
     def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
-                 device_resident=True, M=None, Minv=None, chains_per_subject=1):
+                 device_resident=True, M=None, Minv=None, chains_per_subject=1, device_momenta=None):
         from . import _lib
         super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
         self.device_resident = bool(device_resident)
+        # device_momenta: the host only draws the standard normals z; p0 = chol(M) z and the end point's kinetic energy
+        # 1/2 p1^T M^-1 p1 are formed on the device (nmgp_svc_batch_traj_z).  Default: on whenever a mass matrix is set -- the
+        # host's share of a dense-mass sample was two [B, P] x [P, P] NumPy products -- off for the identity (where it would only
+        # change the summation order of 1/2 |p|^2 against the host-side loop the tests compare with bit for bit).
+        self.device_momenta = (self.mass_kind != 0) if device_momenta is None else bool(device_momenta)
         self.ctx = ctx if ctx is not None else _lib.default_context()
         keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
         self.hyper = np.array([float(hyper_pars[k]) for k in keys])
@@ -485,15 +490,24 @@ class BatchedHMC(LockStepHMC):
         samples = np.zeros((sample_size, B, P))
         U, _ = self.potential_and_grad(self.q)           # leaves q and dU/dq resident
         self.ctx.svc_batch_traj_set_mass(None if self.mass_kind == 0 else self.Minv)
+        if self.device_momenta and self.mass_kind != 0:
+            self.ctx.svc_batch_traj_set_mass_chol(self.Mchol)
         self.ctx.svc_batch_traj_begin()
         accepted = np.zeros(B)
         energy_err = np.zeros((sample_size, B))
         for it in range(sample_size):
-            p0 = self.draw_momenta()
-            H0 = U + self.kinetic(p0)
-            q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
+            if self.device_momenta:
+                # the same random stream: chain b draws its P standard normals, then (below) the accept uniform
+                z = np.stack([r.standard_normal(P) for r in self.rngs])
+                H0 = U + 0.5 * (z * z).sum(1)            # p0 = chol(M) z  =>  1/2 p0^T M^-1 p0 = 1/2 |z|^2
+                q1, K1, U1, failed = self.ctx.svc_batch_traj_z(self.hyper, True, self.eps, self.L, z)
+            else:
+                p0 = self.draw_momenta()
+                H0 = U + self.kinetic(p0)
+                q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
+                K1 = self.kinetic(p1)
             U1 = np.where(failed, np.inf, U1)
-            H1 = U1 + self.kinetic(p1)
+            H1 = U1 + K1
             with np.errstate(invalid="ignore"):       # inf - inf: start and end potential both undefined
                 dH = H1 - H0
             u = np.array([np.log(r.random()) for r in self.rngs])

@@ -318,10 +318,17 @@ def test_batched_hmc_with_a_mass_matrix_on_the_device():
     diag = 1e4 * np.exp(0.5 * rng.standard_normal(P))
     x, Y = torch.from_numpy(g["x"]), torch.from_numpy(g["Y"])
     for kind, Mm in (("diag", diag), ("dense", dense)):
-        dev = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm)
+        dev = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm, device_momenta=False)
         sd, idv = dev.run(S)
         host = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm, device_resident=False)
         sh, ih = host.run(S)
+        # the default with a mass matrix: momenta p0 = chol(M) z and the end point's kinetic energy formed on the device
+        # (nmgp_svc_batch_traj_z) -- same random streams, same trajectories; only the summation order of the energies differs
+        dz = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-3, num_steps_in_leap=L, seed=11, M=Mm)
+        assert dz.device_momenta
+        sz, iz = dz.run(S)
+        assert np.allclose(sz, sh, rtol=1e-10, atol=1e-12), kind
+        assert np.allclose(iz["energy_error"], ih["energy_error"], rtol=0, atol=1e-8) and np.array_equal(iz["accept_rate"], ih["accept_rate"])
         assert np.all(idv["accept_rate"] >= 0.5) and np.nanmax(np.abs(idv["energy_error"])) < 1.0
         assert not np.allclose(sd[-1], init)                        # the chains moved
         if kind == "diag":
@@ -336,10 +343,15 @@ def test_batched_hmc_with_a_mass_matrix_on_the_device():
             assert np.allclose(single, sd[:, b, :], rtol=1e-9, atol=1e-11), (kind, b)
     # back to the identity: the mass matrix is per-run state of the context
     ident = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-5, num_steps_in_leap=L, seed=11)
+    assert not ident.device_momenta
     si, _ = ident.run(2)
     ref = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-5, num_steps_in_leap=L, seed=11, device_resident=False)
     sr, _ = ref.run(2)
     assert np.array_equal(si, sr)
+    # ... and the identity with device-side energies: p0 = z
+    iz = BatchedHMC(g["x"], g["Y"], h, init, step_size=5e-5, num_steps_in_leap=L, seed=11, device_momenta=True)
+    sz, _ = iz.run(2)
+    assert np.allclose(sz, sr, rtol=1e-12, atol=1e-14)
 
 
 @pytest.mark.gpu

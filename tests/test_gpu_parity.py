@@ -383,6 +383,39 @@ def test_prediction_many_grid_points_on_a_fresh_context():
     assert np.allclose(Ls, Lo, rtol=1e-6, atol=1e-6)
 
 
+def test_nonseparable_prediction_at_the_headline_size_against_the_oracle(ctx):
+    """predict_svc at N = 2048, D = 3 on the reference's 201-point grid (prediction.py:912-1012 as called from
+    Nonseparable_model.py:333) -- the size tools/pred_bench.py times: eight grid points against the CPU oracle (one 6144^2
+    factorisation on the host), and the whole grid against the same call made in two slices of the grid, so that results do not
+    depend on how many cross-covariance rows ride in one factorisation.  Mean / variance within 1e-5."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from oracle import nmgp_oracle as O
+    N, M = 2048, 3
+    d = sim.simulate_nonseparable(N, M, seed=2222)
+    p = sim.perturb(d["pars_true"], 0.05, 0.3)
+    h = sim.HYPER_SVC
+    hv = [h[k] for k in SVC_KEYS]
+    xs = np.linspace(0.0, 1.0, 201)
+    ctx.set_data(d["x"], d["Y"])
+    mean, var, Ls = ctx.predict_svc(p, hv, xs)
+    assert mean.shape == (201, M) and var.shape == (201, M) and np.all(var > 0)
+    m1, v1, L1 = ctx.predict_svc(p, hv, xs[:100])
+    m2, v2, L2 = ctx.predict_svc(p, hv, xs[100:])
+    ms, vs, Lss = np.concatenate([m1, m2]), np.concatenate([v1, v2]), np.concatenate([L1, L2])
+    slice_mean = float(np.max(np.abs(mean - ms) / (np.abs(ms) + 1e-2)))
+    slice_var = float(np.max(np.abs(var - vs) / vs))
+    assert np.allclose(mean, ms, rtol=1e-9, atol=1e-11) and np.allclose(var, vs, rtol=1e-9, atol=1e-12) and np.allclose(Ls, Lss, rtol=1e-9, atol=1e-12)
+    pick = np.array([0, 7, 50, 99, 100, 137, 188, 200])
+    tl, uL, tse = O.vec2pars_SVC(p, N, M)
+    _, Lo, mo, vo = O.predmap_inhomogeneous(tl, uL, tse, d["Y"], d["x"], xs[pick], h["mu_tilde_l"], h["alpha_tilde_l"], h["beta_tilde_l"],
+                                            h["mu_L"], h["alpha_L"], h["beta_L"])
+    record_parity("pred_svc_N2048_M3_grid201_oracle",
+                  mean=(float(np.max(np.abs(mean[pick] - mo) / (np.abs(mo) + 1e-2))), 1e-5),
+                  var=(float(np.max(np.abs(var[pick] - vo) / vo)), 1e-5), slices_mean=slice_mean, slices_var=slice_var)
+    assert np.allclose(mean[pick], mo, rtol=1e-5, atol=1e-7) and np.allclose(var[pick], vo, rtol=1e-5, atol=1e-9)
+    assert np.allclose(Ls[pick], Lo, rtol=1e-6, atol=1e-6)
+
+
 def test_batch_with_two_different_prior_factors_equals_single_chain_evaluations(ctx):
     """Chains of ONE subject whose GP priors on l~ and on uL have different hyper-parameters (the reference's _distributed
     scripts: alpha 5, beta_tilde_l 0.1, beta_L 0.2, Nonseparable_model_distributed.py:47-48) share two prior factors: the batch

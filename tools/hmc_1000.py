@@ -1,0 +1,198 @@
+"""BASELINE config 3 as worded: the nonseparable GP at N = 2048, D = 3 on one MI355X, 1000 MCMC iterations.
+
+    python tools/hmc_1000.py [--chains 8] [--iters 1000] [--pilot 100] [--mass diag|identity] [--step auto|<eps>]
+                             [--out gpurun_out/hmc_1000.json] [--progress gpurun_out/hmc_1000.progress]
+
+The sampler call of Nonseparable_model.py:228-231 (HMC, 20 leapfrog steps per iteration, started from the MAP estimate,
+duplicate_samples=True) run for `--chains` chains of the bench subject in lock-step (drivers.BatchedHMC: trajectories resident in
+HBM, one batched value+gradient launch sequence per leapfrog step).  The reference's production runs pass a mass matrix derived
+from a previous run (Nonseparable_model_mpiKAISER.py:398-411); here: `--pilot` identity-mass iterations from the MAP point give a
+per-parameter scale, M = diag(1 / var) (momenta and energies on the device, nmgp_svc_batch_traj_z).  The step size is chosen by a
+short search for ~0.8 acceptance (`--step auto`; the reference's 1e-4 is rejected every time at this size: profiles/r03_hmc_steps.txt).
+
+Writes one JSON document: acceptance, quantiles of |dH|, samples/s and gradient evaluations/s of the main run, effective sample
+size (per chain, summed over chains; Geyer's initial positive sequence on the FFT autocorrelation) and split-R-hat per parameter
+block (l~(x), the T columns of uL(x), log sigma^2), the posterior mean of l~(x) against the generating curve and the MAP estimate,
+and the rms distance the chains travelled."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nonstationary_multivariate_gaussian_process_amd import drivers, sim  # noqa: E402
+
+
+def autocorr_ess(x):
+    """x [S, C, K]: S draws of C chains for K parameters -> ESS [K] (sum over chains of the per-chain ESS)."""
+    S = x.shape[0]
+    xc = x - x.mean(0, keepdims=True)
+    nfft = 1 << (2 * S - 1).bit_length()
+    f = np.fft.rfft(xc, n=nfft, axis=0)
+    ac = np.fft.irfft(f * np.conj(f), n=nfft, axis=0)[:S]
+    var0 = ac[0].copy()
+    var0[var0 <= 0] = np.inf
+    rho = ac / var0
+    # Geyer: sum of adjacent pairs while positive
+    pairs = rho[0:S - (S % 2):2] + rho[1:S - (S % 2) + 1:2]
+    pos = np.cumprod(pairs > 0, axis=0).astype(bool)
+    tau = -1.0 + 2.0 * np.where(pos, pairs, 0.0).sum(0)
+    tau = np.maximum(tau, 1.0 / S)
+    ess = S / tau
+    return np.minimum(ess, S).sum(0)
+
+
+def split_rhat(x):
+    """x [S, C, K] -> split-R-hat [K]."""
+    S = x.shape[0] // 2 * 2
+    h = S // 2
+    y = np.concatenate([x[:h], x[h:S]], axis=1)            # [h, 2C, K]
+    m = y.mean(0)
+    W = y.var(0, ddof=1).mean(0)
+    Bv = h * m.var(0, ddof=1)
+    W = np.where(W <= 0, np.nan, W)
+    return np.sqrt(((h - 1) / h * W + Bv / h) / W)
+
+
+def block_stats(v):
+    v = np.asarray(v, dtype=np.float64)
+    v = v[np.isfinite(v)]
+    q = np.quantile(v, [0.0, 0.05, 0.5, 0.95, 1.0]) if v.size else [np.nan] * 5
+    return {"min": float(q[0]), "q05": float(q[1]), "median": float(q[2]), "q95": float(q[3]), "max": float(q[4]),
+            "mean": float(v.mean()) if v.size else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chains", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--pilot", type=int, default=100)
+    ap.add_argument("--mass", choices=["diag", "identity"], default="diag")
+    ap.add_argument("--step", default="auto")
+    ap.add_argument("--leap", type=int, default=20)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hmc_1000.json"))
+    ap.add_argument("--progress", default=os.path.join(ROOT, "gpurun_out", "hmc_1000.progress"))
+    a = ap.parse_args()
+    N, M, seed = 2048, 3, 2222
+    T = M * (M + 1) // 2
+    B = a.chains
+    d = sim.simulate_nonseparable(N, M, seed=seed)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "map_N%d_M%d_seed%d.npz" % (N, M, seed)))
+    qmap = g["pars_map"]
+    P = qmap.shape[0]
+    q0 = np.repeat(qmap[None], B, 0)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+
+    def note(msg):
+        with open(a.progress, "a") as f:
+            f.write("%s %s\n" % (time.strftime("%H:%M:%S"), msg))
+        print(msg, flush=True)
+
+    rec = {"config": "BASELINE config 3: nonseparable GP, D = 3, N = 2048 (P = %d), one MI355X, %d HMC iterations x %d chains in "
+                     "lock-step, %d leapfrog steps per iteration, start = MAP estimate (tests/golden/%s)" % (
+                         P, a.iters, B, a.leap, "map_N%d_M%d_seed%d.npz" % (N, M, seed)),
+           "reference_call": "Nonseparable_model.py:228-231 (step_size 1e-4, num_steps_in_leap 20, identity mass)"}
+    eps_id = 4e-5
+    mass_kw = {}
+    if a.mass == "diag":
+        t0 = time.time()
+        hp = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q0, step_size=eps_id, num_steps_in_leap=a.leap, seed=100)
+        sp, ip = hp.run(a.pilot)
+        dtp = time.time() - t0
+        # per-parameter scale: mean squared displacement from the start over the second half of the pilot, all chains
+        half = sp[a.pilot // 2:]
+        var = ((half - qmap[None, None]) ** 2).mean((0, 1))
+        # regularise: the pilot barely moves the slow directions -- keep the ratio of scales within 1e4 and smooth within blocks
+        var = np.clip(var, var.max() * 1e-8, None)
+        rec["pilot"] = {"iterations": a.pilot, "step_size": eps_id, "seconds": dtp, "accept_rate_mean": float(ip["accept_rate"].mean()),
+                        "scale_quantiles": block_stats(np.sqrt(var))}
+        q_start = sp[-1]                                   # continue from where the pilot ended
+        mass_kw = {"M": 1.0 / var, "Minv": var}
+        note("pilot: %d iterations in %.1f s, accept %.2f, scale median %.2e" % (a.pilot, dtp, ip["accept_rate"].mean(), np.sqrt(np.median(var))))
+    else:
+        q_start = q0
+    # step size: short search for ~0.8 acceptance
+    if a.step == "auto":
+        # diag mass: the drift per step is eps * scale_i * z_i, so eps is in units of the pilot's scales; start where the median
+        # parameter moves as far per step as under the identity mass at eps_id
+        base = eps_id if a.mass == "identity" else eps_id / float(np.sqrt(np.median(mass_kw["Minv"])))
+        cands = [base * f for f in ((0.5, 1.0, 2.0) if a.mass == "identity" else (0.5, 1.0, 2.0, 4.0, 8.0, 16.0))]
+        tried = []
+        best = None
+        for eps in cands:
+            hs = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=200, **mass_kw)
+            _, isr = hs.run(4)
+            acc = float(isr["accept_rate"].mean())
+            med = float(np.nanmedian(np.abs(isr["energy_error"])))
+            tried.append({"step_size": eps, "accept_rate_mean": acc, "median_abs_dH": med})
+            note("step search: eps %.3g accept %.2f median |dH| %.3g" % (eps, acc, med))
+            if acc >= 0.7:
+                best = eps
+            elif best is not None:
+                break
+        eps = best if best is not None else cands[0]
+        rec["step_search"] = tried
+    else:
+        eps = float(a.step)
+    rec["step_size"] = eps
+    rec["mass"] = ("diagonal, M = 1 / (mean squared displacement of the pilot), momenta and energies on the device (nmgp_svc_batch_traj_z)"
+                   if a.mass == "diag" else "identity")
+    hm = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=1, **mass_kw)
+    # run in segments so that progress is visible
+    seg = 50
+    chunks, accs, ees = [], [], []
+    t0 = time.time()
+    done = 0
+    while done < a.iters:
+        k = min(seg, a.iters - done)
+        s, info = hm.run(k)
+        chunks.append(s)
+        accs.append(info["accept_rate"] * k)
+        ees.append(info["energy_error"])
+        done += k
+        note("main: %d / %d iterations, %.1f s, accept so far %.3f" % (done, a.iters, time.time() - t0, np.sum(accs) / (done * B)))
+    dt = time.time() - t0
+    S = np.concatenate(chunks)                              # [iters, B, P]
+    ee = np.concatenate(ees)
+    acc = np.sum(accs, 0) / a.iters
+    # (every hm.run() call re-evaluates the start point once: iters / seg extra evaluations, counted)
+    evals = (a.iters * a.leap + len(chunks)) * B
+    rec["main"] = {"iterations": a.iters, "chains": B, "seconds": dt, "samples_per_s": a.iters * B / dt,
+                   "grad_evals_per_s": evals / dt, "accept_rate_by_chain": acc.tolist(), "accept_rate_mean": float(acc.mean()),
+                   "abs_dH": block_stats(np.abs(ee)), "dH_mean": float(np.nanmean(ee))}
+    # diagnostics on the second half (the first half as burn-in)
+    Sb = S[a.iters // 2:]
+    blocks = {"tilde_l": np.arange(N)}
+    for t in range(T):
+        blocks["uL_col%d" % t] = N + np.arange(N) * T + t
+    blocks["log_sigma2"] = np.array([P - 1])
+    diag = {}
+    for name, idx in blocks.items():
+        ess = autocorr_ess(Sb[:, :, idx])
+        rh = split_rhat(Sb[:, :, idx])
+        diag[name] = {"ess": block_stats(ess), "split_rhat": block_stats(rh),
+                      "posterior_sd": block_stats(Sb[:, :, idx].reshape(-1, idx.size).std(0))}
+    rec["diagnostics_second_half"] = {"draws_per_chain": int(Sb.shape[0]), "chains": B, "blocks": diag,
+                                      "note": "ESS = sum over chains of S / tau (Geyer initial positive sequence); at most draws x chains"}
+    tl_true = d["pars_true"][:N]
+    tl_mean = Sb[:, :, :N].mean((0, 1))
+    rec["tilde_l_curve"] = {"rms_posterior_mean_minus_truth": float(np.sqrt(np.mean((tl_mean - tl_true) ** 2))),
+                            "rms_map_minus_truth": float(np.sqrt(np.mean((qmap[:N] - tl_true) ** 2))),
+                            "rms_posterior_mean_minus_map": float(np.sqrt(np.mean((tl_mean - qmap[:N]) ** 2))),
+                            "at_x": [float(v) for v in d["x"][::256]], "truth": [float(v) for v in tl_true[::256]],
+                            "posterior_mean": [float(v) for v in tl_mean[::256]], "map": [float(v) for v in qmap[:N][::256]],
+                            "posterior_sd": [float(v) for v in Sb[:, :, :N].reshape(-1, N).std(0)[::256]]}
+    rec["rms_displacement_from_start_per_parameter"] = float(np.sqrt(np.mean((S[-1] - q_start) ** 2)))
+    rec["log_sigma2"] = {"truth": float(d["pars_true"][-1]), "map": float(qmap[-1]), "posterior_mean": float(Sb[:, :, -1].mean()),
+                         "posterior_sd": float(Sb[:, :, -1].std())}
+    with open(a.out, "w") as f:
+        json.dump(rec, f, indent=1)
+    note("wrote %s: %.2f samples/s, accept %.3f" % (a.out, rec["main"]["samples_per_s"], acc.mean()))
+
+
+if __name__ == "__main__":
+    main()
