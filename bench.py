@@ -409,17 +409,33 @@ def run_chains(a, rank, world, be):
         evals = (1 + 20 * a.hmc_samples) * B
         ee = info["energy_error"]
         moved = float(np.sqrt(np.mean((samples[-1] - q0) ** 2)))
-        hmc_rec = {"what": "BatchedHMC: %d chains in lock-step, %d samples per chain, 20 leapfrog steps per sample, step size %g, "
-                           "%s (the sampler call of Nonseparable_model.py:228-231, whose step 1e-4 is too coarse at this size: "
-                           "profiles/r03_hmc_steps.txt); one batched value+gradient evaluation per leapfrog "
-                           "step; positions, momenta and gradients stay in HBM for the whole trajectory (nmgp_svc_batch_traj), per "
-                           "sample the momenta go up and the end point comes down" % (B, a.hmc_samples, a.hmc_step, mass_note),
+        # every rank's own sampler evidence (ranks other than 0 have no committed MAP point: their chains start from perturbed
+        # parameters -- descent trajectories, always accepted -- and the record must not pass rank 0's figures off as theirs)
+        mine = {"rank": rank, "start": "MAP estimate" if mp is not None else "perturbed generating parameters (no MAP point committed)",
+                "accept_rate_mean": float(np.mean(info["accept_rate"])), "accept_rate_min": float(np.min(info["accept_rate"])),
+                "median_abs_energy_error": float(np.nanmedian(np.abs(ee))), "max_abs_energy_error": float(np.nanmax(np.abs(ee))),
+                "rms_displacement_per_parameter": moved}
+        by_rank = [mine]
+        if _dist_on(world):
+            import torch.distributed as dist
+            by_rank = [None] * dist.get_world_size()
+            dist.all_gather_object(by_rank, mine)
+        hmc_rec = {"what": "BatchedHMC: %d chains in lock-step, %d samples per chain, 20 leapfrog steps per sample, %s (the sampler call "
+                           "of Nonseparable_model.py:228-231); one batched value+gradient evaluation per leapfrog step; positions, momenta "
+                           "and gradients stay in HBM for the whole trajectory (nmgp_svc_batch_traj / _traj_z), per sample the momenta "
+                           "(or their standard normals) go up and the end point comes down" % (B, a.hmc_samples, mass_note),
+                   "step_size": a.hmc_step / (2.0 if a.hmc_mass != "identity" else 1.0),
+                   "reference_step_size": 1e-4,
+                   "step_size_note": "the reference's 1e-4 (Nonseparable_model.py:229) is rejected every time from the MAP point at this "
+                                     "size (P = 14,337: energy error +8.0, profiles/r03_hmc_steps.txt); the default here is 4e-5",
+                   "long_run": "profiles/r04_hmc_1000.json: BASELINE config 3 as worded -- 1000 iterations at this size (tools/hmc_1000.py)",
                    "start": start,
                    "samples_per_s": a.hmc_samples * B * world / h_elapsed, "samples_per_chain": a.hmc_samples,
                    "seconds": h_elapsed, "grad_evals_per_s": evals * world / h_elapsed,
-                   "accept_rate_mean": float(np.mean(info["accept_rate"])), "accept_rate_min": float(np.min(info["accept_rate"])),
-                   "median_abs_energy_error": float(np.nanmedian(np.abs(ee))), "max_abs_energy_error": float(np.nanmax(np.abs(ee))),
-                   "rms_displacement_per_parameter": moved}
+                   "accept_rate_mean": float(np.mean([r["accept_rate_mean"] for r in by_rank])),
+                   "accept_rate_min": float(np.min([r["accept_rate_min"] for r in by_rank])),
+                   "median_abs_energy_error": mine["median_abs_energy_error"], "max_abs_energy_error": mine["max_abs_energy_error"],
+                   "rms_displacement_per_parameter": moved, "by_rank": by_rank}
     # the ONE reduction: every chain of every rank contributes a row
     ids = [rank * B + b for b in range(B)]
     stats, table = chains.reduce_rows(unit_rows(ids, a.steps, out, status), B * world, world, device=be.device)

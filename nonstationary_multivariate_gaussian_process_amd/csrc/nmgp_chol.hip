@@ -2091,7 +2091,7 @@ static void factor_panel_fused(hipStream_t s, double* A, int lda, int n, int ext
         // (absolute row n + extra + r) enters with step r / 64 of its panel; its column block k + 1 is first touched by the
         // solve role of that step and of the next one, everything further right by the update role one step later
         const int un_fresh = xtri > 0 ? n + extra + (has_prev ? ck - 64 : ck) : 0x7fffffff;
-        const int u_tri = xtri > 0 ? n + extra - 192 : 0x7fffffff;
+        const int u_tri = xtri > 0 ? n + extra - 64 * NMGP_XTRI_SEED_BLOCKS : 0x7fffffff;
         if (leaf && pl.tiles == 0 && !pre && nk == 2) {
             static const int occ1 = [] { const char* e = std::getenv("NMGP_LEAF1_OCC"); return e ? std::atoi(e) : 4; }();
             static const int occ2 = [] { const char* e = std::getenv("NMGP_LEAF2_OCC"); return e ? std::atoi(e) : 6; }();
@@ -2343,6 +2343,11 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
 // Everything right of the diagonal block is written by the factorisation before it is read: a row enters the factorisation
 // with the panel its index lies in, and the update kernels start such "fresh" rows from zero instead of loading them
 // (syrk_tile_fast & co.: fresh0; k_panel_step: un_fresh, u_tri).  Everything further left is never touched.
+// reach of the readers left of a row's own 64-column block: update tiles skip leading zero k-panels per 128-row TILE in pairs of
+// 16-column panels (SY_BM + 2 SY_BK - 2 columns left of the diagonal at most), the inverse SYRK starts at the tile's first row
+// (SY_BM - 1), k_panel_step's u_tri = n + extra - 192 assumes exactly three seeded blocks
+static_assert(SY_BM + 2 * SY_BK - 2 <= 64 * NMGP_XTRI_SEED_BLOCKS, "update tiles of L^-T rows would read left of the seeded band");
+static_assert(NMGP_XTRI_SEED_BLOCKS == 3, "k_panel_step (u_tri) and k_xtri_seed's grid (4 column blocks per row block) assume three seeded blocks");
 __global__ __launch_bounds__(256) void k_xtri_seed(double* __restrict__ A, int lda, int row0, int n, int pad,
                                                     long long bstride) {
     A += (size_t)blockIdx.z * bstride;
@@ -2354,7 +2359,7 @@ __global__ __launch_bounds__(256) void k_xtri_seed(double* __restrict__ A, int l
     }
     const int b = blockIdx.x;                                // 64-row block of X; blockIdx.y = which of the four 64-column blocks
     const int r = 64 * b + lane;
-    const int cb = b - 3 + (int)blockIdx.y;
+    const int cb = b - NMGP_XTRI_SEED_BLOCKS + (int)blockIdx.y;
     if (cb < 0 || r >= n) return;
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
@@ -2363,7 +2368,7 @@ __global__ __launch_bounds__(256) void k_xtri_seed(double* __restrict__ A, int l
     }
 }
 void identity_rows(hipStream_t s, double* A, int lda, int row0, int n, int pad, int batch, long long bstride) {
-    NMGP_LAUNCH(k_xtri_seed, dim3(cdiv_c(n, 64) + 1, 4, batch), dim3(256), 0, s, A, lda, row0, n, pad, bstride);
+    NMGP_LAUNCH(k_xtri_seed, dim3(cdiv_c(n, 64) + 1, NMGP_XTRI_SEED_BLOCKS + 1, batch), dim3(256), 0, s, A, lda, row0, n, pad, bstride);
 }
 
 }  // namespace nmgpk

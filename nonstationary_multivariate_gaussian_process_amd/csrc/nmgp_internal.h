@@ -298,6 +298,12 @@ void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const do
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
                 int xstride = 0, int cps = 1);
+// The rows of L^-T of a gradient evaluation are seeded only in a band (k_xtri_seed, nmgp_chol.hip): the identity in a row's own
+// 64-column block and zeros in the NMGP_XTRI_SEED_BLOCKS blocks left of it.  Every reader of those rows reaches a bounded distance
+// left of the diagonal; nmgp_chol.hip and nmgp_kernels.hip static_assert their reach against this constant, so that a change of
+// tile size or block width cannot silently read unwritten memory (which only NMGP_POISON would show).
+#define NMGP_XTRI_SEED_BLOCKS 3
+#define NMGP_TRI_GEMV_BLOCK 256     // block edge of tri_gemv_upper (reads the 256 x 256 blocks on and above the diagonal)
 // out = W z, W upper triangular (n x n, column-major with leading dimension ld; the zeros left of the diagonal are stored);
 // part: n * ceil(n / 256) doubles of scratch per matrix
 void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double* z, double* out, double* part, int batch = 1,

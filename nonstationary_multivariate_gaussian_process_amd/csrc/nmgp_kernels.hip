@@ -5,6 +5,7 @@
 // Matrices handed to rocSOLVER/rocBLAS are column-major with the LOWER triangle stored; because every
 // such matrix is symmetric this is the same memory image as the reference's row-major upper triangle.
 #include "nmgp_internal.h"
+#include <mutex>
 
 namespace nmgpk {
 
@@ -408,6 +409,10 @@ __global__ __launch_bounds__(256) void k_tri_gemv_reduce(const double* __restric
     out[(size_t)blockIdx.y * n + i] = a;
 }
 
+// (row r of a diagonal block reads columns from the block's first one on: at most NMGP_TRI_GEMV_BLOCK - 64 + r % 64 left of r's own
+// 64-column block start -- inside the seeded band)
+static_assert(NMGP_TRI_GEMV_BLOCK == 256, "k_tri_gemv_part / _reduce are written for 256-wide blocks");
+static_assert(NMGP_TRI_GEMV_BLOCK <= 64 * (NMGP_XTRI_SEED_BLOCKS + 1), "tri_gemv_upper would read left of the band k_xtri_seed writes");
 // part: at least n * ceil(n / 256) doubles per matrix, `pstride` apart
 void tri_gemv_upper(hipStream_t s, const double* W, int ld, int n, const double* z, double* out, double* part, int batch,
                     long long wstride, long long pstride) {
@@ -1066,12 +1071,22 @@ void prior_trsv(hipStream_t s, bool trans, const double* L0, int ld0, long long 
     const size_t lds = ((size_t)N + 2 + 64 * 65 + 64) * sizeof(double);
     if (cps < 1) cps = 1;
     if (lds > 64 * 1024) {
-        // beyond the default 64 KB of dynamic LDS (N > 3966): opt in to the CU's 160 KB once (prediction at config 5's N = 4096)
-        static bool raised = false;
-        if (!raised) {
-            raised = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // beyond the default 64 KB of dynamic LDS (N > 3966): opt in to the CU's 160 KB (prediction at config 5's N = 4096).  The
+        // attribute belongs to the CURRENT device: one flag per device ordinal (contexts on several GPUs of one process), set only
+        // once the runtime has accepted it -- a refusal is reported through the launch that follows (NMGP_LAUNCH records it) and
+        // retried on the next call.  (A context belongs to one host thread; the flags are written under a mutex all the same.)
+        static std::mutex mu;
+        static bool raised[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_prior_trsv<false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised[dev] = (e0 == hipSuccess && e1 == hipSuccess);
+            if (!raised[dev]) (void)hipGetLastError();
         }
     }
     if (trans)

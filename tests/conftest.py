@@ -47,8 +47,11 @@ def vec_relerr(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-def prior_term_err(a, b, N):
-    """Error measure for the verbose GP-prior components (lp_l, lp_uL) at sizes where they are a small difference of
+def prior_component_err_on_the_logdet_scale(a, b, N):
+    """RELAXED measure (the name says so in every assertion and in the parity table's column): the verbose GP-prior COMPONENTS are
+    checked against max(|component|, N/2 |log 1e-6|), not against |component| alone; the log posterior -- their sum with the
+    likelihood -- is always held to the plain 1e-6 relative bar next to it.
+    Error measure for the verbose GP-prior components (lp_l, lp_uL) at sizes where they are a small difference of
     large terms: each is -N/2 log 2pi - 1/2 log det - 1/2 q with 1/2 |log det| ~ N/2 |log jitter| (most eigenvalues of
     RBF + 1e-6 I sit at the jitter floor), so the error is taken relative to max(|component|, that scale).  The log
     posterior itself (their sum with the likelihood) is always checked at the plain 1e-6 relative north-star bar."""
@@ -83,7 +86,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "parity_%s.json" % os.environ.get("NMGP_ROUND", "r02"))
+    path = os.path.join(out_dir, "parity_%s.json" % os.environ.get("NMGP_ROUND", "r04"))
     worst = {}
     for row in _PARITY:
         for k, v in row.items():

@@ -80,12 +80,38 @@ def test_profile_tools_replay_the_launch_schedule_of_the_throughput_path():
     finally:
         syrk_classes.LEAF = old
     assert len(leaf) == 47 and len(full) == 95           # the launch counts in profiles/r03_batched128_last_eval.txt / r02
-    assert sorted(set(k for _, _, k in full)) == [64, 128, 256, 512, 1024, 2048]
-    assert sorted(set(k for _, _, k in leaf)) == [128, 256, 512, 1024, 2048]
+    assert sorted(set(t[2] for t in full)) == [64, 128, 256, 512, 1024, 2048]
+    assert sorted(set(t[2] for t in leaf)) == [128, 256, 512, 1024, 2048]
     assert [t for t in full if t[2] != 64] == leaf       # the leaves only remove the K = 64 launches
+    assert all(c1 - c0 == k for _, _, k, c0, c1 in full)  # K = width of the panel [c0, c1) being applied
 
     def flop(sched):
-        return sum(2.0 * k * (nc * m - 0.5 * nc * (nc - 1)) for m, nc, k in sched)
+        return sum(2.0 * k * (nc * m - 0.5 * nc * (nc - 1)) for m, nc, k, _, _ in sched)
     # all update launches together: n^3/3 minus the diagonal blocks and panel solves (98.5 % at n = 6144, one extra row)
     assert 0.98 < flop(full) / (n ** 3 / 3.0) < 0.99
     assert 0.96 < flop(leaf) / (n ** 3 / 3.0) < flop(full) / (n ** 3 / 3.0)
+    # value evaluation: executed flop == nominal flop, launch by launch
+    assert all(syrk_classes.launch_flop(m, nc, k, c0, c1, n, 1, 0) == 2.0 * k * (nc * m - 0.5 * nc * (nc - 1)) for m, nc, k, c0, c1 in leaf)
+    # value+gradient evaluation (n rows of L^-T ride below): the tiles of those rows skip their leading zero k-panels, so the
+    # executed flop of a launch is below 2 K x elements (what round 3's table counted: 88.7 / 93.6 "TFLOP/s" at K = 2048) and the
+    # total lies between the structural minimum 2 n^3/3 (less the leaves' share) and the nominal count
+    g = syrk_classes.schedule(n, nb1, 2, n)
+    ex = sum(syrk_classes.launch_flop(m, nc, k, c0, c1, n, 2, n) for m, nc, k, c0, c1 in g)
+    nom = flop(g)
+    assert len(g) == 47 and ex < nom and 0.95 * (2 * n ** 3 / 3.0) < ex < 1.03 * (2 * n ** 3 / 3.0) and nom > 1.12 * (2 * n ** 3 / 3.0)
+    big = [t for t in g if t[2] == 2048]
+    assert all(syrk_classes.launch_flop(*t, n, 2, n) < 0.9 * 2.0 * t[2] * (t[1] * t[0] - 0.5 * t[1] * (t[1] - 1)) for t in big)
+
+
+def test_committed_class_tables_never_exceed_the_matrix_peak():
+    """Every per-class TFLOP/s figure of the committed round-4 tables (tools/syrk_classes.py output under profiles/) is at most the FP64
+    matrix peak: a figure above it means the timed kernel is not doing the counted work."""
+    import glob
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*syrk_classes.txt")))
+    for f in files:
+        for ln in open(f):
+            for v in re.findall(r"([0-9.]+) TF/s", ln):
+                assert float(v) <= bench.FP64_MATRIX_PEAK_TFLOPS, (f, ln)

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (SEP_KEYS, STA_KEYS, SVC_KEYS, golden, golden_names, hyper_dict, prior_term_err, relerr,
+from conftest import (SEP_KEYS, STA_KEYS, SVC_KEYS, golden, golden_names, hyper_dict, prior_component_err_on_the_logdet_scale, relerr,
                       vec_relerr)
 from oracle import nmgp_oracle as O
 
@@ -104,7 +104,7 @@ def test_config4_subjects_at_full_size():
             r, grad = O.nlogpos_obj_SVC(g[pk][s], g["Ys"][s], g["xs"][s], **h, verbose=True, formulation="cholesky", grad=True)
             assert relerr(r[0], g[ok][s][0]) < VAL_TOL, (s, pk, r, g[ok][s])
             assert relerr(r[1], g[ok][s][1]) < 1e-9 and relerr(r[4], g[ok][s][4]) < 1e-12
-            assert prior_term_err(r[2:4], g[ok][s][2:4], g["xs"].shape[1]) < VAL_TOL
+            assert prior_component_err_on_the_logdet_scale(r[2:4], g[ok][s][2:4], g["xs"].shape[1]) < VAL_TOL
             assert vec_relerr(grad, g[gk][s]) < GRAD_TOL
 
 
