@@ -77,25 +77,40 @@ def measured_traffic(N, M, chains, want_grad=False, workload="chain"):
 
 # ---- product backend: libnmgp_hip.so on one MI355X per rank, RCCL between ranks -------------------------------------
 class HipBackend:
-    """One process per GPU.  Everything that touches HIP / torch.cuda / RCCL lives here."""
+    """One process per GPU.  Everything that touches HIP / torch.cuda / RCCL lives here.
+
+    `rehearse` (bench.py --rehearse-on-one-gpu): the multi-process path on a box with FEWER GPUs than ranks -- rank r drives GPU
+    r mod visible, the process group is gloo and the few control-plane collectives run on CPU tensors (RCCL refuses two ranks on
+    one device).  Everything else is the product path: N processes launched the same way, each loading libnmgp_hip.so, creating
+    its context and streams and running the real evaluations.  The line says `rehearsal`, and its value is not a scaling
+    figure (the ranks share a card)."""
     device = "cuda"
 
-    def __init__(self, local_rank):
+    def __init__(self, local_rank, rehearse=False):
         import torch
         self.torch = torch
-        self.local_rank = local_rank
+        self.rehearse = bool(rehearse)
         ndev = torch.cuda.device_count()
-        if local_rank >= ndev:
+        if ndev <= 0:
+            raise SystemExit("bench.py: no GPU is visible (the MI355X path has no CPU fallback)")
+        if local_rank >= ndev and not rehearse:
             raise SystemExit("bench.py: LOCAL_RANK=%d but this process sees %d GPU(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES "
                              "= %r / %r): one rank per GPU needs --nproc-per-node <= visible GPUs" % (
                                  local_rank, ndev, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
-        torch.cuda.set_device(local_rank)
+        self.rank_local = local_rank
+        self.local_rank = local_rank % ndev          # the device ordinal this rank drives
+        if rehearse:
+            self.device = "cpu"                      # where the control-plane collectives' tensors live
+        torch.cuda.set_device(self.local_rank)
 
     def device_count(self):
         return self.torch.cuda.device_count()
 
     def init_dist(self, rank, world):
         import torch.distributed as dist
+        if self.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            return
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=self.torch.device("cuda", self.local_rank))
 
@@ -111,7 +126,7 @@ class HipBackend:
         if hasattr(pr, "pci_bus_id"):
             pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
         from nonstationary_multivariate_gaussian_process_amd import _lib
-        return {"local_rank": self.local_rank, "torch_current_device": int(t.cuda.current_device()), "name": pr.name,
+        return {"local_rank": self.rank_local, "device_ordinal": self.local_rank, "torch_current_device": int(t.cuda.current_device()), "name": pr.name,
                 "pci_bus_id": pci, "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid(),
                 "visible_devices": int(t.cuda.device_count()), "library_build_id": _lib.build_id()}
 
@@ -676,6 +691,10 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=1,
                     help="split the chains into this many groups, each a batched context on its own pair of HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run --gpus N ranks on a box with fewer GPUs: rank r drives GPU r mod visible, gloo process group, collectives "
+                         "on CPU tensors (RCCL refuses two ranks on one device); exercises launch, per-rank contexts and the reduction "
+                         "on hardware -- not a scaling measurement (the line carries `rehearsal`: true)")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="with ONE rank: initialise the process group anyway (RCCL) and run the barrier / max / gather / reduction "
                          "through it -- the part of the multi-GPU path a single-GPU box can execute")
@@ -696,7 +715,7 @@ def main(argv=None, backend=None):
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (`python bench.py --gpus N` does it by itself, "
                          "or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)" % (a.gpus, world))
-    be = backend if backend is not None else HipBackend(local_rank)
+    be = backend if backend is not None else HipBackend(local_rank, rehearse=a.rehearse_on_one_gpu)
     global DIST_ACTIVE
     if world > 1 or a.dist_selftest:
         # --dist-selftest: ONE rank initialises the process group as well (RCCL on the HIP backend), so that the barrier, the
@@ -714,6 +733,10 @@ def main(argv=None, backend=None):
         extra = rec.pop("config_extra", None)
         if extra:
             rec["config"].update(extra)
+        if a.rehearse_on_one_gpu:
+            rec["rehearsal"] = True
+            rec["rehearsal_note"] = ("ranks share GPU(s) (rank r -> GPU r mod visible) and talk gloo: a functional rehearsal of the "
+                                     "multi-process path, NOT a scaling measurement")
         if RANK_IDS and RANK_IDS[0].get("library_build_id"):
             rec["config"]["library_build_id"] = RANK_IDS[0]["library_build_id"]      # == build.tree_id() of the sources (_lib.load checks)
         print(json.dumps(rec), flush=True)

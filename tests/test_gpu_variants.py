@@ -214,3 +214,27 @@ def test_blocked_triangular_inversion_agrees_with_the_riding_rows_and_the_oracle
                 assert all(s == 0 for s in a["status"])
                 assert relerr(np.array(a["batch"]), np.array(b["batch"])) < 1e-7, (env_extra, key)
                 assert vec_relerr(np.array(a["bgrad"]), np.array(b["bgrad"])) < 1e-7, (env_extra, key)
+
+
+def test_bench_launches_two_ranks_by_itself_and_rehearses_the_multi_process_path_on_one_gpu():
+    """`python bench.py --gpus 2 --rehearse-on-one-gpu` with no torch.distributed environment: bench.py starts its own two ranks (a
+    child `python -m torch.distributed.run`, before anything touches the GPU), each rank loads the library, creates its context and
+    streams on the box's one GPU and runs the real evaluations; barrier, max-over-ranks, gathers and the final reduction go through a
+    gloo process group (RCCL refuses two ranks on one device).  What a one-GPU box can execute of the N > 1 path, as one command."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--chains", "3", "--N", "96",
+                          "--steps", "2", "--warmup", "1", "--grad-steps", "1", "--hmc-samples", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    dr = rec["distributed"]
+    assert rec["n_gpus"] == 2 and rec["rehearsal"] is True and dr["self_launched"] is True
+    assert dr["process_group"] == {"backend": "gloo", "world_size": 2, "rank": 0}
+    assert [r["rank"] for r in dr["ranks"]] == [0, 1] and [r["local_rank"] for r in dr["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in dr["ranks"]}) == 2 and all(r["device_ordinal"] == 0 for r in dr["ranks"])
+    assert len({r["library_build_id"] for r in dr["ranks"]}) == 1 and dr["distinct_gpus"] == 1
+    assert rec["config"]["chains_total"] == 6 and rec["config"]["chains_ok"] == 6 and rec["grad"]["chains_ok"] == 3
+    assert len(rec["hmc"]["by_rank"]) == 2 and rec["hmc"]["by_rank"][1]["rank"] == 1
+    assert "cpu_baseline" not in rec
