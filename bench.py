@@ -415,7 +415,7 @@ def run_chains(a, rank, world, be):
                 mass_kw = {"M": Mm, "Minv": Minv}
             mass_note = "%s mass matrix (synthetic, M^-1 ~ %g I), resident on the device" % (a.hmc_mass, sc)
         hmc = drivers.BatchedHMC(d["x"], d["Y"], hyper, q0, step_size=a.hmc_step / (2.0 if a.hmc_mass != "identity" else 1.0),
-                                 num_steps_in_leap=20, seed=1, ctx=prof, **mass_kw)
+                                 num_steps_in_leap=20, seed=1, ctx=prof, device_momenta=True, **mass_kw)
         barrier(be, ev, world)
         t0 = time.perf_counter()
         samples, info = hmc.run(a.hmc_samples)

@@ -24,6 +24,10 @@ cp $O/traffic.json profiles/traffic.json
 tail -1 $O/bench_default.json > profiles/${P}_default_bench.json
 [ -f gpurun_out/parity_${P}.json ] && cp gpurun_out/parity_${P}.json profiles/parity_${P}.json
 cp $O/batched128_timeline.txt profiles/${P}_batched128_timeline.txt 2>/dev/null || true
+cp $O/batched128_syrk_classes.txt profiles/${P}_batched128_syrk_classes.txt 2>/dev/null || true
+for t in v128 g128; do
+    [ -f $O/${t}_pmc_mfma.json ] && cp $O/${t}_pmc_mfma.json profiles/${P}_${t}_pmc_mfma.json && cp $O/${t}_pmc_MFMA_BUSY.csv profiles/${P}_${t}_pmc_MFMA_BUSY.csv
+done
 # the value+gradient step (tools/profile_grad.sh)
 if [ -f $O/g128_kernel_stats.csv ]; then
     for f in kernel_stats.csv last_eval.txt syrk_classes.txt timeline.txt pmc_FETCH_SIZE.csv pmc_WRITE_SIZE.csv pmc_traffic.json pmc_syrk_classes.json; do

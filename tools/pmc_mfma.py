@@ -1,6 +1,6 @@
 """MFMA utilisation of k_syrk_lower from a rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES).
 
-usage: python tools/pmc_mfma.py <counter_collection.csv> [out.json]
+usage: python tools/pmc_mfma.py <counter_collection.csv> [out.json] [end marker, default k_svc_finalize; k_svc_grad_final for value+gradient]
 Per launch of the LAST evaluation: duration, effective clock (GRBM_GUI_ACTIVE / 8 XCDs / duration) and the MFMA-busy share
 of the SIMD cycles, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * duration * clock)."""
 import csv
@@ -16,7 +16,8 @@ for r in rows:
     by[d][r["Counter_Name"]] = float(r["Counter_Value"])
     meta[d] = (r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
 ids = sorted(meta)
-fin = [d for d in ids if "k_svc_finalize" in meta[d][0]]
+MARK = sys.argv[3] if len(sys.argv) > 3 else "k_svc_finalize"
+fin = [d for d in ids if MARK in meta[d][0]]
 lo = fin[-2] if len(fin) > 1 else ids[0]
 out = []
 for d in ids:
@@ -33,7 +34,11 @@ for d in ids:
 big = sorted(out, key=lambda o: -o["us"])[:6]
 tot = sum(o["us"] for o in out)
 avg_util = sum(o["mfma_busy_share"] * o["us"] for o in out) / tot if tot else 0.0
-res = {"launches": len(out), "total_us": tot, "time_weighted_mfma_busy_share": avg_util, "largest_launches": big}
+avg_clk = sum(o["clock_ghz"] * o["us"] for o in out) / tot if tot else 0.0
+res = {"what": "k_syrk_lower launches of the last evaluation (end marker %s): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock), "
+               "clock = GRBM_GUI_ACTIVE / 8 XCDs / duration" % MARK,
+       "launches": len(out), "total_us": tot, "time_weighted_mfma_busy_share": avg_util, "time_weighted_clock_ghz": avg_clk,
+       "clock_limited_peak_tflops": 78.6 * avg_clk / 2.4, "largest_launches": big}
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 2:
     json.dump(res, open(sys.argv[2], "w"), indent=1)

@@ -33,6 +33,6 @@ cd "$R"
 python3 tools/pmc_summary.py "$O/${t}_pmc_FETCH_SIZE.csv" "$O/${t}_pmc_WRITE_SIZE.csv" "$O/${t}_pmc_traffic.json" "$B chains value+gradient, $1" k_svc_grad_final
 python3 tools/pmc_classes.py "$O/${t}_pmc_FETCH_SIZE.csv" "$O/${t}_pmc_WRITE_SIZE.csv" "$O/${t}_pmc_syrk_classes.json" 6144 2048 "$B" grad
 # pin the measured traffic of the value+gradient step (bench.py's grad.roofline.traffic) to the kernel source it was measured on
-mkdir -p profiles && cp "$O/${t}_pmc_traffic.json" "profiles/${3:-r03}_${t}_pmc_traffic.json"
-python3 tools/pin_traffic.py "profiles/${3:-r03}_${t}_pmc_traffic.json" 2048 3 "$B" 1 chain && cp profiles/traffic.json "$O/traffic.json"
+mkdir -p profiles && cp "$O/${t}_pmc_traffic.json" "profiles/${3:-r04}_${t}_pmc_traffic.json"
+python3 tools/pin_traffic.py "profiles/${3:-r04}_${t}_pmc_traffic.json" 2048 3 "$B" 1 chain && cp profiles/traffic.json "$O/traffic.json"
 tail -1 "$O/$t.json" | cut -c1-600

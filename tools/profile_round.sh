@@ -21,6 +21,9 @@ trace() {      # trace <tag> <marker> <program args...>
     if [ "$marker" != "-" ]; then
         python3 "$R/tools/trace_summary.py" "$(find "$O/raw_$tag" -name '*kernel_trace.csv' | head -1)" "$marker" > "$O/${tag}_last_eval.txt"
         python3 "$R/tools/timeline.py" "$O/raw_$tag" "$marker" > "$O/${tag}_timeline.txt"
+        if [ "$tag" = "batched128" ]; then
+            python3 "$R/tools/syrk_classes.py" "$(find "$O/raw_$tag" -name '*kernel_trace.csv' | head -1)" 6144 2048 128 0 > "$O/${tag}_syrk_classes.txt"
+        fi
     fi
     rm -rf "$O/raw_$tag"
     echo "traced $tag"
