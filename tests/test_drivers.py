@@ -355,6 +355,55 @@ def test_batched_hmc_with_a_mass_matrix_on_the_device():
 
 
 @pytest.mark.gpu
+def test_trajectory_state_is_invalidated_by_a_new_metric_or_new_subjects():
+    """The resident trajectory state (positions, gradients, flags) belongs to the metric and the data it was begun under:
+    nmgp_svc_batch_traj_set_mass after nmgp_svc_batch_traj_begin, or new subjects after the start evaluation, must make the next
+    trajectory call fail with a state error instead of continuing with a stale gradient; momenta cannot be drawn on the device
+    before chol(M) is there."""
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    g = golden("svc_rngfree_N32_M2")
+    hv = g["hyper"]
+    B = 2
+    c = _lib.Context(0)
+    try:
+        c.set_data(g["x"], g["Y"])
+        c.svc_batch_alloc(B)
+        q = np.stack([sim.perturb(g["pars"], 0.01, 0.3 * b) for b in range(B)])
+        P = q.shape[1]
+        z = np.random.default_rng(0).standard_normal((B, P))
+
+        def start():
+            c.svc_batch_set_pars(q)
+            c.svc_batch_eval(hv, True, want_grad=True)
+            c.svc_batch_traj_begin()
+        start()
+        q1, p1, U1, failed = c.svc_batch_traj(hv, True, 1e-5, 2, z)          # fine
+        assert np.all(np.isfinite(U1)) and not failed.any()
+        # a new metric after begin: the trajectory must be begun again
+        c.svc_batch_traj_set_mass(np.full(P, 2.0))
+        with pytest.raises(_lib.NmgpError, match="traj_begin"):
+            c.svc_batch_traj(hv, True, 1e-5, 2, z)
+        start()
+        # device-side momenta need chol(M) for the metric in force
+        with pytest.raises(_lib.NmgpError, match="chol"):
+            c.svc_batch_traj_z(hv, True, 1e-5, 2, z)
+        c.svc_batch_traj_set_mass_chol(np.full(P, np.sqrt(0.5)))
+        qz, kin, Uz, fz = c.svc_batch_traj_z(hv, True, 1e-5, 2, z)
+        assert np.all(np.isfinite(kin)) and np.all(kin > 0) and not fz.any()
+        c.svc_batch_traj_commit(np.ones(B, dtype=bool))
+        # new subjects: the resident gradient no longer belongs to the batch -- begin needs a fresh evaluation
+        c.svc_batch_set_subjects(np.stack([g["x"]] * B), np.stack([g["Y"]] * B))
+        with pytest.raises(_lib.NmgpError, match="value\\+gradient evaluation"):
+            c.svc_batch_traj_begin()
+        c.svc_batch_traj_set_mass(None)
+        start()
+        q2, _, U2, f2 = c.svc_batch_traj(hv, True, 1e-5, 2, z)
+        assert np.all(np.isfinite(U2)) and not f2.any()
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_one_hmc_chain_per_subject_equals_the_subjects_sampled_one_at_a_time():
     """BatchedHMC over a multi-subject batch (x [B, N], Y [B, N, M]: config 4's unit, every subject with its own data and
     prior factors) against the same sampler run on each subject alone with the same random stream."""
