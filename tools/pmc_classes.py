@@ -14,7 +14,7 @@ import sys
 from collections import OrderedDict
 
 sys.path.insert(0, __file__.rsplit("/", 1)[0])
-from syrk_classes import schedule  # noqa: E402
+from syrk_classes import launch_flop, schedule  # noqa: E402
 
 
 def last_eval_syrk(path, marker="k_svc_finalize"):
@@ -41,13 +41,13 @@ def main():
     if len(f) != len(sched) or len(w) != len(sched):
         raise SystemExit("launch count mismatch: fetch %d, write %d, schedule %d" % (len(f), len(w), len(sched)))
     cls = OrderedDict()
-    for (m, nc, K), fk, wk in zip(sched, f, w):
+    for (m, nc, K, c0, c1), fk, wk in zip(sched, f, w):
         elems = nc * m - 0.5 * nc * (nc - 1)
         c = cls.setdefault("K=%d" % K, {"launches": 0, "measured_bytes": 0.0, "algorithmic_bytes": 0.0, "flop": 0.0})
         c["launches"] += 1
         c["measured_bytes"] += 1024.0 * (2.0 * fk + wk)
         c["algorithmic_bytes"] += 8.0 * batch * (2.0 * elems + m * K)
-        c["flop"] += 2.0 * K * elems * batch
+        c["flop"] += launch_flop(m, nc, K, c0, c1, n, extra, n if grad else 0) * batch        # EXECUTED flop (zero k-panels skipped)
     if inv is not None:
         # -Sigma^-1 = -X X^T: reads the upper-triangular X once (8 n^2 / 2), writes both triangles of the result (8 n^2)
         cls["inverse (K=n)"] = {"launches": 1, "measured_bytes": 1024.0 * (2.0 * inv[0] + inv[1]),
