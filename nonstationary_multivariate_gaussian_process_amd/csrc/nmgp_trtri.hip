@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, 4) void k_tri_gemm(double* __restrict__ S, int
     double* sB0 = smem + 2 * SBUF;
     const int ti = mrows >> 7, tj = ncols >> 7;
     int bi, bj, p, bz;
-    if (lock) {
+    if (lock == 1) {
         // XCD-lockstep order (needs npairs * nbatch % 8 == 0).  Workgroup id t runs on XCD t % 8 and ids are dispatched in order, so
         // XCD x is given the matrices x, x + 8, ... and walks, for every 8 x 8 block of tiles (longest blocks first), its matrices one
         // after the other: at any time all XCDs work on the SAME block position of different matrices (equal k-lengths: no XCD holds
@@ -84,6 +84,21 @@ __global__ __launch_bounds__(512, 4) void k_tri_gemm(double* __restrict__ S, int
         const int mat = ml * 8 + x;
         p = mat % npairs;
         bz = mat / npairs;
+    } else if (lock == 2) {
+        // matrix-major order: all tiles of one (matrix, pair) before the next -- the chip works on one matrix at a time, whose operands
+        // then live in the Infinity Cache (the order of the inverse SYRK); inside, longest tile rows / columns first
+        const int id = blockIdx.x, tpm = ti * tj;
+        const int mat = id / tpm, tin = id - mat * tpm;
+        p = mat % npairs;
+        bz = mat / npairs;
+        if (MODE == 0) {
+            bi = tin / tj;
+            bj = tin - bi * tj;
+        } else {
+            const int u = tin / ti;
+            bj = tj - 1 - u;
+            bi = tin - u * ti;
+        }
     } else {
         const int id = blockIdx.x;
         if (MODE == 0) {
@@ -311,15 +326,20 @@ __global__ __launch_bounds__(256) void k_trtri_leaf128(double* __restrict__ S, i
 static void tri_gemm_pair(hipStream_t s, double* S, int ld, long long bs, int batch, int xoff, int a0, int a1, int a2, int npairs,
                           long long pstride, const SyrkHook* hook) {
     const int m1 = a1 - a0, m2 = a2 - a1;
-    // NMGP_TRTRI_ORDER=lockstep: the XCD-lockstep tile order (L2 reuse of the operand panels) instead of equal-length tiles
-    // consecutive.  Measured, 128 chains: factorisation + inversion 312.9 ms (rows) against 315.3-316.8 (lockstep) -- at 4.3 TB/s of
-    // operand traffic through the fabric these launches are still not bound by it
+    // Tile order (NMGP_TRTRI_ORDER).  Default `matrix`: all tiles of one (matrix, pair) before the next, longest tile rows / columns
+    // first inside -- the chip then works on one matrix at a time, whose operands live in the 256 MB Infinity Cache (the order of
+    // the inverse SYRK).  `rows`: tiles of equal k-length consecutive ACROSS matrices (the working set is a tile row of all 128
+    // matrices: it streams from HBM).  `lockstep`: XCD x owns the matrices x, x + 8, ... and all XCDs walk the same 8 x 8 tile block
+    // (L2 reuse of the operand panels, eight matrices live).  Measured, 128 chains, factorisation + inversion: matrix 313.2 ms,
+    // rows 320.0 (312.9 on a faster box), lockstep +2.4-3.9 ms on rows; the same lockstep order costs the inverse SYRK 8 %.  What
+    // these launches want is Infinity-Cache locality, not L2 reuse.
     static const int order_env = [] {
         const char* e = std::getenv("NMGP_TRTRI_ORDER");
-        return (e && std::strcmp(e, "lockstep") == 0) ? 1 : 0;
+        return (e && std::strcmp(e, "lockstep") == 0) ? 1 : ((e && std::strcmp(e, "rows") == 0) ? 0 : 2);
     }();
     const int t1 = m1 / 128, t2 = m2 / 128;
-    const int lock = (order_env && ((long long)npairs * batch) % 8 == 0 && (t1 < 8 || t1 % 8 == 0) && (t2 < 8 || t2 % 8 == 0)) ? 1 : 0;
+    const int lock = order_env == 2 ? 2
+                     : ((order_env == 1 && ((long long)npairs * batch) % 8 == 0 && (t1 < 8 || t1 % 8 == 0) && (t2 < 8 || t2 % 8 == 0)) ? 1 : 0);
     // T' = -X[a0:a1, a0:a1] L[a1:a2, a0:a1]^T  -> rows a0.., columns a1.. of the factor's region (strictly upper: scratch)
     {
         void* tok = nullptr;

@@ -203,7 +203,7 @@ def test_blocked_triangular_inversion_agrees_with_the_riding_rows_and_the_oracle
         return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     ref = run({"NMGP_TRTRI": "0"})
     for env_extra in ({"NMGP_TRTRI": "1"}, {"NMGP_TRTRI": "1", "NMGP_POISON": "1"}, {"NMGP_TRTRI": "1", "NMGP_CHOL_FUSED_MAX_BATCH": "0"},
-                      {"NMGP_TRTRI": "1", "NMGP_TRTRI_ORDER": "lockstep"}):
+                      {"NMGP_TRTRI": "1", "NMGP_TRTRI_ORDER": "lockstep"}, {"NMGP_TRTRI": "1", "NMGP_TRTRI_ORDER": "rows"}):
         r = run(env_extra)
         for key, a in r.items():
             b = ref[key]
