@@ -173,6 +173,16 @@ int nmgp_logpos_sep(nmgp_ctx* ctx, const double* pars, const double hyper[9], in
 int nmgp_logpos_sta(nmgp_ctx* ctx, const double* pars, const double hyper[5], int prior,
                     double out5[5], double* grad);
 
+/* B chains of the SEPARABLE model of the resident subject per launch sequence -- the unit the reference runs as separate processes
+ * (Separable_model_mpisim.py:299-300) and the potential evaluations of its sampler (Separable_model.py:209): chain b's M blocks
+ * wB_b[p] K_x,b + sigma2_b I join ONE batch of the blocked Cholesky (B M matrices of order N), as do the triangular products and the
+ * inverse SYRK of the gradient; objective of logpos.py:216-296 per chain.
+ * pars [B, 2N+T+1]; out6 [B, 6] (as nmgp_logpos_sep); grad [B, 2N+T+1] or NULL; status [B]: 0 = exact covariance, k in 1..3 = the
+ * chain needed k jitter retries (re-evaluated through nmgp_logpos_sep: the reference's `while loglik != loglik` loop), another
+ * positive code = numerical failure even so (its out6 row is NaN).  Returns 0 unless an API / runtime error occurred. */
+int nmgp_sep_batch_eval(nmgp_ctx* ctx, const double* pars, int B, const double hyper[9], int prior, double* out6, double* grad,
+                        int* status);
+
 /* ---- primitives (host buffers in / out) ----------------------------------------------------- */
 /* kernels.pairwise_distances, kernels.py:5-21.  x1: [n1,d], x2: [n2,d] or NULL (=x1). out: [n1,n2]. */
 int nmgp_pairwise_distances(nmgp_ctx* ctx, const double* x1, int n1, const double* x2, int n2, int d,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "nmgp_svc_covariance": (I, [V, P, P]),
     "nmgp_logpos_sep": (I, [V, P, P, I, P, P]),
     "nmgp_logpos_sta": (I, [V, P, P, I, P, P]),
+    "nmgp_sep_batch_eval": (I, [V, P, I, P, I, P, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_pairwise_distances": (I, [V, P, I, P, I, I, P]),
     "nmgp_rbf_cov": (I, [V, P, I, P, I, I, D, D, P]),
     "nmgp_nonstat_rbf_cov": (I, [V, P, P, P, I, P, P, P, I, I, P]),
@@ -379,6 +380,22 @@ class Context:
         grad = np.empty(P_) if want_grad else None
         self.check(self.lib.nmgp_logpos_sep(self.h, ptr(pars), ptr(hyper), int(bool(prior)), ptr(out), ptr(grad)))
         return out, grad
+
+    def sep_batch_eval(self, pars, hyper, prior=True, want_grad=False):
+        """B chains of the separable model in one launch sequence: pars [B, 2N+T+1] -> (out [B, 6], grad [B, P] or None,
+        status [B]: 0 exact, 1..3 jitter retries needed, other positive = numerical failure (row NaN))."""
+        pars = as_f64(pars)
+        P_ = 2 * self.N + self.T + 1
+        if pars.ndim != 2 or pars.shape[1] != P_:
+            raise NmgpError("parameters must be [B, 2N+T+1 = %d], got %s" % (P_, pars.shape))
+        hyper = as_f64(hyper)
+        B = pars.shape[0]
+        out = np.empty((B, 6))
+        grad = np.empty((B, P_)) if want_grad else None
+        status = np.zeros(B, dtype=np.int32)
+        self.check(self.lib.nmgp_sep_batch_eval(self.h, ptr(pars), B, ptr(hyper), int(bool(prior)), ptr(out), ptr(grad),
+                                                status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out, grad, status
 
     def logpos_sta(self, pars, hyper, prior=True, want_grad=False):
         pars = as_f64(pars).reshape(-1)

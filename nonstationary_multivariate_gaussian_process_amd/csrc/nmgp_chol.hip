@@ -2269,7 +2269,7 @@ void potrf_lower(hipStream_t s, hipStream_t s2, hipEvent_t* ev, double* A, int l
     // n = 3072, slower for one chain or 8 subjects; with the L^-T rows (gradient) 2048 wins since their zero k-panels are skipped
     // (234.6 against 233.6 evals/s at 64 chains)
     if (nb1 <= 0)
-        nb1 = (batch >= 16 && n >= 6144) ? 2048
+        nb1 = (batch >= 16 && n >= 4096) ? 2048         // (n = 4096: 80 blocks of the batched separable model 418.9 -> 430.6 evals/s)
               : (((batch >= 4 && n >= 4096) || (batch >= 32 && n >= 2048)) && (long long)batch * n > 73728) ? 1024 : 512;
     // (batches small enough for the fused panel steps keep 512: separable N = 4096, D = 5: 4.39 ms against 4.55 with 1024)
     const int is = istride;

@@ -556,6 +556,258 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
 }
 
 // =================================================================================================
+// separable objective, B chains of the resident subject per launch sequence
+// =================================================================================================
+// The chains of the separable model's MCMC (the reference runs them one process each: Separable_model_mpisim.py:299-300;
+// every HMC iteration asks for the objective of logpos.py:216-296 once per leapfrog step) as ONE batch of the blocked Cholesky:
+// chain b contributes its M blocks S_bp = wB_b[p] K_x,b + sigma2_b I, so B chains are B M matrices of order N in every launch of
+// the factorisation, of the triangular matrix-vector product and of the inverse SYRK -- the launches that hold > 90 % of an
+// evaluation -- while the small per-chain pieces (M x M eigendecomposition on the host, covariance build, block assembly,
+// adjoint pass) are queued chain by chain on the same stream.  One chain's 5 blocks of N = 4096 are latency-bound (0.37 of the
+// FP64 matrix roofline); 16 chains are 80 matrices on the throughput schedule.  Cholesky formulation only (NMGP_SEP=eig falls back
+// to chain-by-chain evaluation).  A chain whose covariance fails numerically is re-evaluated through nmgp_logpos_sep, i.e. with
+// the reference's jitter retries (status[b] = the retries it needed; negative-free: API errors fail the call).
+// pars [B, 2N+T+1]; out6 [B, 6]; grad [B, P] or NULL; status [B]: 0 exact, k > 0 evaluated with k jitter retries,
+// NMGP_NUM_NAN / a leading-minor index if even those failed (out6 row NaN).
+extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const double hyper[9], int prior, double* out6,
+                                   double* grad, int* status) {
+    if (!c) return NMGP_E_NULL;
+    if (!pars || !hyper || !out6 || !status) return nmgp_fail(c, NMGP_E_NULL, "pars/hyper/out6/status must not be NULL");
+    if (B <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "B must be positive");
+    NMGP_TRY(require_data(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, M = c->M, T = c->T;
+    const size_t P = (size_t)2 * N + T + 1;
+    const bool want_grad = grad != nullptr;
+    auto one_by_one = [&](int b) -> int {
+        int rc = nmgp_logpos_sep(c, pars + (size_t)b * P, hyper, prior, out6 + (size_t)b * 6, want_grad ? grad + (size_t)b * P : nullptr);
+        if (rc < 0) return rc;
+        if (rc > 0) {
+            for (int k = 0; k < 6; ++k) out6[(size_t)b * 6 + k] = std::nan("");
+            if (want_grad) for (size_t k = 0; k < P; ++k) grad[(size_t)b * P + k] = 0.0;
+            status[b] = rc;
+        } else {
+            status[b] = c->last_sep_attempts;
+        }
+        return 0;
+    };
+    if (c->sep_algo != 1 || B == 1) {
+        for (int b = 0; b < B; ++b) NMGP_TRY(one_by_one(b));
+        return 0;
+    }
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_s = hyper[3], al_s = hyper[4], be_s = hyper[5];
+    const double a = hyper[6], bb = hyper[7], cc = hyper[8];
+    hipStream_t s = c->stream;
+    NMGP_TRY(ensure_eig_buffers(c, N));
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    // ---- device memory: one slab, carved ----
+    const int BM = B * M;
+    const int xpad = (N + 1) & 1, xoff = N + 1 + xpad;
+    const int ld = want_grad ? (int)((((size_t)2 * N + 2 + 15) / 16) * 16) : (int)((((size_t)N + 1 + 15) / 16) * 16);
+    const long long bs = (long long)ld * N;
+    const size_t NN = (size_t)N * N;
+    const size_t small_per = (size_t)M + (size_t)M * M + 2;        // wB | VB (row-major) | sigma2 | pad
+    const int NJ = (N + 63) / 64;
+    const size_t tri_part = (size_t)N * ((N + 255) / 256);
+    const int G = NMGP_SEP_TR_G;                                    // partial sums per block that sep_traces leaves for the host
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 1) & ~(size_t)1; return o; };
+    const size_t o_P = take((size_t)B * P), o_ell = take((size_t)B * N), o_sig = take((size_t)B * N), o_K = take((size_t)B * NN);
+    const size_t o_small = take((size_t)B * small_per), o_yt = take((size_t)BM * N), o_z = take((size_t)BM * N);
+    const size_t o_alpha = take((size_t)BM * N), o_red = take((size_t)BM * 4), o_info = take((size_t)BM);
+    const size_t o_R = take((size_t)N * 2 * B), o_R2 = take((size_t)N * 2 * B), o_q = take((size_t)2 * B + 2);
+    const size_t o_S = take((size_t)BM * bs);
+    size_t o_Cneg = 0, o_part = 0, o_C = 0, o_W = 0, o_Xi = 0, o_g = 0, o_tr = 0;
+    if (want_grad) {
+        o_Cneg = take((size_t)BM * NN);
+        o_part = take(std::max((size_t)BM * tri_part, (size_t)NJ * N * 2 + 8));
+        o_C = take(NN);
+        o_W = take((size_t)N * M);
+        o_Xi = take((size_t)B * M * M);
+        o_g = take((size_t)B * 2 * N);
+        o_tr = take((size_t)BM * G * 3);
+    }
+    double* slab;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, off, &slab));      // (the single-chain path's slot: the two never run at the same time)
+    double *dP = slab + o_P, *d_ell = slab + o_ell, *d_sig = slab + o_sig, *dK = slab + o_K, *d_small = slab + o_small;
+    double *yt = slab + o_yt, *z = slab + o_z, *alpha = slab + o_alpha, *red = slab + o_red;
+    int* info = reinterpret_cast<int*>(slab + o_info);
+    double *R = slab + o_R, *R2 = slab + o_R2, *dq = slab + o_q, *S = slab + o_S;
+    // ---- host: B, its eigendecomposition, per chain ----
+    std::vector<EigWork> w(B);
+    std::vector<double> hsmall((size_t)B * small_per, 0.0), sig2(B), tse(B);
+    for (int b = 0; b < B; ++b) {
+        const double* pb = pars + (size_t)b * P;
+        tse[b] = pb[P - 1];
+        sig2[b] = std::exp(tse[b]);
+        build_B(pb + 2 * N, M, true, w[b].h_L, w[b].h_B);
+        jacobi_eigh(M, w[b].h_B.data(), w[b].h_wB, w[b].h_VB);
+        double* h = hsmall.data() + (size_t)b * small_per;
+        for (int p = 0; p < M; ++p) h[p] = w[b].h_wB[p];
+        for (int k = 0; k < M * M; ++k) h[M + k] = w[b].h_VB[k];
+        h[M + (size_t)M * M] = sig2[b];
+    }
+    HIP_TRY(c, hipMemcpyAsync(dP, pars, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(info, 0, (size_t)BM * sizeof(int), s));
+    PriorStreamScope pscope(c);
+    {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        for (int b = 0; b < B; ++b) {
+            const double* sm = d_small + (size_t)b * small_per;
+            exp_vec(s, dP + (size_t)b * P, N, d_ell + (size_t)b * N);
+            exp_vec(s, dP + (size_t)b * P + N, N, d_sig + (size_t)b * N);
+            gibbs_cov_sym(s, c->d_x, d_sig + (size_t)b * N, d_ell + (size_t)b * N, N, dK + (size_t)b * NN, N, false);
+            rotate_y(s, c->d_Y, sm + M, N, M, yt + (size_t)b * M * N);
+            sep_blocks(s, dK + (size_t)b * NN, sm, sm + M + (size_t)M * M, N, M, S + (size_t)b * M * bs, ld, bs);
+        }
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_CHOL);
+        set_row(s, S, ld, N, yt, N, BM, bs, N);
+        if (want_grad) identity_rows(s, S, ld, N + 1, N, xpad, BM, bs);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, N), S, ld, N, want_grad ? 1 + xpad : 1, want_grad ? N : 0, c->chol_nb1, info,
+                    BM, bs, 1, nmgp_syrk_hook(c));
+        get_row(s, S, ld, N, z, N, BM, bs, N);
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_REDUCE);
+        chol_logdet_quad(s, S, ld, N, z, red, red + 1, BM, bs, 4);
+    }
+    {
+        // GP priors on tilde_l and tilde_sigma of every chain: 2 B right-hand sides against the cached factors
+        NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
+        for (int b = 0; b < B; ++b)
+            two_col_rhs(pscope.sp, dP + (size_t)b * P, mu_l, dP + (size_t)b * P + N, mu_s, N, R + (size_t)2 * b * N);
+        double* r2 = (want_grad && prior) ? R2 : nullptr;
+        if (pl == ps) {
+            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R, 2 * B, r2));
+        } else {
+            for (int b = 0; b < B; ++b) {
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R + (size_t)2 * b * N, 1, r2 ? r2 + (size_t)2 * b * N : nullptr));
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, R + (size_t)(2 * b + 1) * N, 1, r2 ? r2 + (size_t)(2 * b + 1) * N : nullptr));
+            }
+        }
+        col_sumsq(pscope.sp, R, N, N, 2 * B, dq);
+    }
+    pscope.done();
+    pscope.join();
+    std::vector<double> hr((size_t)BM * 4), hq((size_t)2 * B);
+    std::vector<int> hi(BM);
+    double hl[2];
+    HIP_TRY(c, hipMemcpyAsync(hr.data(), red, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)BM * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hq.data(), dq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&hl[0], pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&hl[1], ps->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::vector<char> bad(B, 0);
+    std::vector<double> lp_uL(B, 0.0), lp_s2(B);
+    std::vector<std::vector<double>> g_uL_prior(B, std::vector<double>(T, 0.0));
+    for (int b = 0; b < B; ++b) {
+        double ll = 0.0;
+        for (int p = 0; p < M; ++p) {
+            if (hi[(size_t)b * M + p] != 0) bad[b] = 1;
+            ll += -0.5 * hr[((size_t)b * M + p) * 4] - 0.5 * hr[((size_t)b * M + p) * 4 + 1];
+        }
+        if (!std::isfinite(ll)) bad[b] = 1;
+        const double* pb = pars + (size_t)b * P;
+        const double lp_l = -0.5 * (N * LOG2PI + hq[(size_t)2 * b]) - hl[0];
+        const double lp_s = -0.5 * (N * LOG2PI + hq[(size_t)2 * b + 1]) - hl[1];
+        for (int t = 0; t < T; ++t) lp_uL[b] += normal_logprob_f32(pb[2 * N + t], 0.0, cc, &g_uL_prior[b][t]);
+        lp_s2[b] = (-a - 1.0) * std::log(sig2[b]) - bb / sig2[b] + a * std::log(bb) - std::lgamma(a);
+        double res = ll;
+        if (prior) { res += lp_l; res += lp_s; res += lp_uL[b]; res += lp_s2[b]; res += tse[b]; }
+        double* o = out6 + (size_t)b * 6;
+        o[0] = -res; o[1] = ll; o[2] = lp_l; o[3] = lp_s; o[4] = lp_uL[b]; o[5] = lp_s2[b];
+        status[b] = 0;
+    }
+    if (want_grad) {
+        double *Cneg = slab + o_Cneg, *part = slab + o_part, *C = slab + o_C, *W = slab + o_W, *Xi = slab + o_Xi, *d_g = slab + o_g;
+        double* trs = slab + o_tr;
+        const double one = 1.0, zero = 0.0;
+        {
+            NmgpStage sp(c, NMGP_STAGE_INVERSE);
+            tri_gemv_upper(s, S + xoff, ld, N, z, alpha, part, BM, bs, (long long)tri_part);
+            syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, BM, bs, (long long)NN, 1);              // -S_bp^-1
+        }
+        int Gs = 0;
+        {
+            NmgpStage sp(c, NMGP_STAGE_ADJOINT);
+            for (int b = 0; b < B; ++b) {
+                if (bad[b]) continue;
+                const double* sm = d_small + (size_t)b * small_per;
+                double* al = alpha + (size_t)b * M * N;
+                const double* Cn = Cneg + (size_t)b * M * NN;
+                Gs = sep_traces(s, Cn, dK + (size_t)b * NN, al, N, M, trs + (size_t)b * M * G * 3);
+                if (Gs != G) return nmgp_fail(c, NMGP_E_STATE, "sep_traces group count %d differs from the batch layout's %d", Gs, G);
+                weighted_sum_lower(s, Cn, sm, N, M, C);
+                fill_lower_to_full(s, C, N, N);
+                sep_adjoint(s, c->d_x, d_ell + (size_t)b * N, d_sig + (size_t)b * N, al, sm, M, C, N, part);
+                sep_grad_sum(s, part, NJ, N, d_g + (size_t)b * 2 * N);
+                HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)N * M * sizeof(double), s));
+                BLAS_TRY(c, rocblas_dsymm(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, dK + (size_t)b * NN, N, al, N, &zero, W, N));
+                BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, al, N, W, N, &zero,
+                                          Xi + (size_t)b * M * M, M));
+            }
+        }
+        std::vector<double> hx((size_t)B * M * M, 0.0), hg((size_t)B * 2 * N, 0.0), hR2((size_t)N * 2 * B, 0.0), htr((size_t)BM * G * 3, 0.0);
+        HIP_TRY(c, hipMemcpyAsync(hx.data(), Xi, hx.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(htr.data(), trs, htr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (prior) HIP_TRY(c, hipMemcpyAsync(hR2.data(), R2, hR2.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int b = 0; b < B; ++b) {
+            if (bad[b]) continue;
+            std::vector<double> tr(M, 0.0), tk(M, 0.0), aa(M, 0.0);
+            // sep_traces wrote M * Gs * 3 doubles contiguously at trs + b * M * G * 3
+            const double* tb = htr.data() + (size_t)b * M * G * 3;
+            for (int p = 0; p < M; ++p)
+                for (int g = 0; g < Gs; ++g) {
+                    tr[p] += tb[((size_t)p * Gs + g) * 3];
+                    tk[p] += tb[((size_t)p * Gs + g) * 3 + 1];
+                    aa[p] += tb[((size_t)p * Gs + g) * 3 + 2];
+                }
+            std::vector<double> Xs((size_t)M * M), dB((size_t)M * M, 0.0), g_uL;
+            const double* hxb = hx.data() + (size_t)b * M * M;
+            for (int p = 0; p < M; ++p)
+                for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (hxb[(size_t)q * M + p] - (p == q ? tk[p] : 0.0));
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j) {
+                    double acc = 0.0;
+                    for (int p = 0; p < M; ++p)
+                        for (int q = 0; q < M; ++q) acc += w[b].h_VB[(size_t)i * M + p] * Xs[(size_t)p * M + q] * w[b].h_VB[(size_t)j * M + q];
+                    dB[(size_t)i * M + j] = acc;
+                }
+            double ds = 0.0;
+            for (int p = 0; p < M; ++p) ds += 0.5 * (aa[p] - tr[p]);
+            dB_to_guL(dB, w[b].h_L, M, g_uL);
+            double* gb = grad + (size_t)b * P;
+            for (int i = 0; i < 2 * N; ++i) {
+                // (R2 holds the chain's two solved columns [tilde_l | tilde_sigma] back to back: the layout of the 2N leading parameters)
+                const double r = prior ? hR2[(size_t)2 * b * N + i] : 0.0;
+                gb[i] = -(hg[(size_t)b * 2 * N + i] - r);
+            }
+            for (int t = 0; t < T; ++t) gb[2 * N + t] = -(g_uL[t] + (prior ? g_uL_prior[b][t] : 0.0));
+            double ge = sig2[b] * ds;
+            if (prior) ge += (-a - 1.0) + bb / sig2[b] + 1.0;
+            gb[P - 1] = -ge;
+        }
+    }
+    NMGP_TRY(nmgp_take_launch_error(c));
+    // chains that failed numerically: the single-chain entry, with the reference's jitter retries
+    for (int b = 0; b < B; ++b)
+        if (bad[b]) NMGP_TRY(one_by_one(b));
+    c->last_sep_attempts = 0;
+    for (int b = 0; b < B; ++b)
+        if (status[b] > 0 && status[b] <= NMGP_SEP_RETRIES && status[b] > c->last_sep_attempts) c->last_sep_attempts = status[b];
+    return 0;
+}
+
+// =================================================================================================
 // stationary objective
 // =================================================================================================
 extern "C" int nmgp_logpos_sta(nmgp_ctx* c, const double* pars, const double hyper[5], int prior, double out5[5],

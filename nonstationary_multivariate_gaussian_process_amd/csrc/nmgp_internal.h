@@ -361,6 +361,7 @@ void add_diag(hipStream_t s, double* A, int ld, int n, double v);
 void rotate_y(hipStream_t s, const double* Y, const double* VB, int N, int M, double* yt);
 void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* sigma2p, int N, int M, double* out,
                 int ldo, long long bstride);
+#define NMGP_SEP_TR_G 128      // partial sums per block that sep_traces leaves for the host: out[(p * NMGP_SEP_TR_G + g) * 3 + {tr, tk, aa}]
 int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double* alpha, int N, int M, double* out);
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
 // ---- nmgp_chol.hip ----

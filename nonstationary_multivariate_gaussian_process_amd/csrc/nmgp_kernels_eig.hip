@@ -685,7 +685,7 @@ void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* 
 // per block p (Cneg_p = -S_p^-1, lower, ld = N) partial sums over the columns j = blockIdx.y, +gridDim.y, ...:
 //   out[(p G + g) 3 + 0] += tr S_p^-1,  [.. + 1] += <S_p^-1, K> (full symmetric inner product from the lower triangles),
 //   [.. + 2] += ||alpha_p||^2 (chunk g = 0 only).  The host adds the G partials (deterministic order).
-#define SEP_TR_G 128
+#define SEP_TR_G NMGP_SEP_TR_G
 __global__ __launch_bounds__(256) void k_sep_traces(const double* __restrict__ Cneg, const double* __restrict__ K,
                                                      const double* __restrict__ alpha, int N,
                                                      double* __restrict__ out) {

@@ -519,3 +519,29 @@ class BatchedHMC(LockStepHMC):
             energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
             samples[it] = self.q
         return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
+
+
+class BatchedHMCSeparable(LockStepHMC):
+    """B independent HMC chains of the SEPARABLE model of one subject in lock-step: every leapfrog step evaluates
+    ``logpos.nlogpos_obj`` and its gradient for all chains with one launch sequence (``nmgp_sep_batch_eval``: the chains' B*M
+    blocks ``wB[p] K_x + sigma2 I`` form one batch of the blocked Cholesky).  The sampler call of ``Separable_model.py:209`` /
+    ``Separable_model_mpiKAISER.py:281`` for B chains at once; chain b reproduces ``HMCSampler(potential_func=logpos.nlogpos_obj,
+    ...)`` started from the same state with the same random stream.  The leapfrog update runs on the host (P = 2N + T + 1)."""
+
+    KEYS = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma", "beta_tilde_sigma", "a", "b", "c")
+
+    def __init__(self, x, Y, hyper_pars, init_positions, step_size=2e-4, num_steps_in_leap=20, seed=None, ctx=None, M=None, Minv=None):
+        from . import _lib
+        super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.hyper = np.array([float(hyper_pars[k]) for k in self.KEYS])
+        self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
+
+    def potential_and_grad(self, q):
+        """U [B] and dU/dq [B, P]; a chain whose covariance stays numerically singular after the jitter retries gets U = inf."""
+        out, g, status = self.ctx.sep_batch_eval(q, self.hyper, True, True)
+        U = out[:, 0].copy()
+        bad = (status > 3) | ~np.isfinite(U)
+        U[bad] = np.inf
+        g[bad] = 0.0
+        return U, g

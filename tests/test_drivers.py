@@ -404,6 +404,31 @@ def test_trajectory_state_is_invalidated_by_a_new_metric_or_new_subjects():
 
 
 @pytest.mark.gpu
+def test_batched_separable_hmc_chains_follow_the_single_chain_sampler():
+    """BatchedHMCSeparable: B chains of the separable model in lock-step on nmgp_sep_batch_eval; every chain reproduces
+    HMCSampler(potential_func=logpos.nlogpos_obj, ...) -- the sampler call of Separable_model.py:209 -- from the same state with the
+    same random stream."""
+    from nonstationary_multivariate_gaussian_process_amd.Utility import logpos
+    from nonstationary_multivariate_gaussian_process_amd.drivers import BatchedHMCSeparable, HMCSampler
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from conftest import SEP_KEYS
+    g = golden("sep_rngfree_N32_M2")
+    h = hyper_dict(g["hyper"], SEP_KEYS)
+    B, S, L = 3, 4, 5
+    init = np.stack([sim.perturb(g["pars"], 0.01 * b, 0.5 * b) for b in range(B)])
+    bh = BatchedHMCSeparable(g["x"], g["Y"], h, init, step_size=2e-4, num_steps_in_leap=L, seed=21)
+    sb, ib = bh.run(S)
+    assert sb.shape == (S, B, init.shape[1]) and np.all(ib["accept_rate"] >= 0.5) and not np.allclose(sb[-1], init)
+    x, Y = torch.from_numpy(g["x"]), torch.from_numpy(g["Y"])
+    for b in range(B):
+        hs = HMCSampler(sample_size=S, potential_func=logpos.nlogpos_obj, init_position=init[b], step_size=2e-4, num_steps_in_leap=L,
+                        Y=Y, x=x, seed=0, **h)
+        hs.rng = np.random.default_rng(21 + b)
+        single, _ = hs.main_hmc_loop()
+        assert np.allclose(single, sb[:, b, :], rtol=1e-9, atol=1e-11), b
+
+
+@pytest.mark.gpu
 def test_one_hmc_chain_per_subject_equals_the_subjects_sampled_one_at_a_time():
     """BatchedHMC over a multi-subject batch (x [B, N], Y [B, N, M]: config 4's unit, every subject with its own data and
     prior factors) against the same sampler run on each subject alone with the same random stream."""

@@ -277,6 +277,60 @@ def test_python_mirror_sep_sta_and_primitives(ctx):
                   gp["invgamma"]) < 1e-14
 
 
+def test_separable_chains_batched_equal_single_chain_evaluations(ctx):
+    """nmgp_sep_batch_eval: B chains of the separable model as ONE batch of B*M blocks (factorisation, triangular products, inverse
+    SYRK batched; the small per-chain pieces queued chain by chain).  Chain 0 carries a reference golden (value + autograd
+    gradient), every chain must equal its single-chain evaluation -- on the fused-step schedule (B*M*N small) and on the throughput
+    schedule (16 chains x 5 blocks of N = 1024: recursive panels, leaf launches, wide outer panels)."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    for name, B in (("sep_rngfree_N64_M3", 4), ("sep_sim_N512_M5", 3)):
+        g = golden(name)
+        ctx.set_data(g["x"], g["Y"])
+        pars = np.stack([sim.perturb(g["pars"], 0.01 * k, 0.4 * k) for k in range(B)])
+        pars[0] = g["pars"]
+        out, grad, st = ctx.sep_batch_eval(pars, g["hyper"], bool(g["prior"]), True)
+        outv, _, stv = ctx.sep_batch_eval(pars, g["hyper"], bool(g["prior"]), False)
+        assert np.all(st == 0) and np.all(stv == 0)
+        record_parity("sepbatch_%s_chain0_vs_golden" % name, neglog=(relerr(out[0][0], g["out"][0]), VAL_TOL),
+                      grad=(vec_relerr(grad[0], g["grad"]), GRAD_TOL))
+        assert relerr(out[0][0], g["out"][0]) < VAL_TOL and vec_relerr(grad[0], g["grad"]) < GRAD_TOL
+        for k in range(B):
+            so, sg = ctx.logpos_sep(pars[k], g["hyper"], bool(g["prior"]), True)
+            assert relerr(out[k][1], so[1]) < 1e-10 and relerr(out[k], so) < 1e-9, (name, k, out[k], so)
+            assert relerr(outv[k], so) < 1e-9
+            assert vec_relerr(grad[k], sg) < 1e-8, (name, k, vec_relerr(grad[k], sg))
+    # throughput schedule
+    N, M, B = 1024, 5, 16
+    d = sim.simulate_separable(N, M, seed=21)
+    hv = [sim.HYPER_SEP[k] for k in SEP_KEYS]
+    pars = np.stack([sim.perturb(d["pars_true"], 0.03, 0.3 + 0.2 * k) for k in range(B)])
+    ctx.set_data(d["x"], d["Y"])
+    out, grad, st = ctx.sep_batch_eval(pars, hv, True, True)
+    assert np.all(st == 0) and np.all(np.isfinite(out)) and np.all(np.isfinite(grad))
+    for k in (0, 7, 15):
+        so, sg = ctx.logpos_sep(pars[k], hv, True, True)
+        record_parity("sepbatch16_N1024_M5_chain%d_vs_single" % k, loglik=(relerr(out[k][1], so[1]), 1e-10), grad=(vec_relerr(grad[k], sg), 1e-8))
+        assert relerr(out[k][1], so[1]) < 1e-10 and relerr(out[k], so) < 1e-9 and vec_relerr(grad[k], sg) < 1e-8
+    # a chain whose covariance is numerically singular (the case of test_separable_and_stationary_objectives_recover_from_a_singular_
+    # covariance: a zero row of B and sigma2 = 0) goes through the single-chain entry's jitter retries; the others are unaffected
+    N, M = 96, 3
+    d = sim.simulate_separable(N, M, 3)
+    good = d["pars_true"].copy()
+    sing = good.copy()
+    T = M * (M + 1) // 2
+    uL = sing[2 * N:2 * N + T].copy()
+    uL[1], uL[2], uL[4] = 0.0, -800.0, 0.0
+    sing[2 * N:2 * N + T] = uL
+    sing[-1] = -800.0
+    ctx.set_data(d["x"], d["Y"])
+    out, grad, st = ctx.sep_batch_eval(np.stack([good, sing, good]), hv, False, True)
+    s_ok, g_ok = ctx.logpos_sep(good, hv, False, True)
+    s_bad, g_bad = ctx.logpos_sep(sing, hv, False, True)
+    assert list(st) == [0, 1, 0], st
+    assert relerr(out[0], s_ok) < 1e-9 and relerr(out[2], s_ok) < 1e-9 and vec_relerr(grad[0], g_ok) < 1e-8
+    assert relerr(out[1][:2], s_bad[:2]) < 1e-12 and np.all(np.isfinite(grad[1])) and vec_relerr(grad[1], g_bad) < 1e-10
+
+
 def test_prediction_against_reference_golden(ctx):
     """North-star tolerance: predictive mean / variance within 1e-5 of the reference."""
     import torch
