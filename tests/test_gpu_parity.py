@@ -311,6 +311,18 @@ def test_separable_chains_batched_equal_single_chain_evaluations(ctx):
         so, sg = ctx.logpos_sep(pars[k], hv, True, True)
         record_parity("sepbatch16_N1024_M5_chain%d_vs_single" % k, loglik=(relerr(out[k][1], so[1]), 1e-10), grad=(vec_relerr(grad[k], sg), 1e-8))
         assert relerr(out[k][1], so[1]) < 1e-10 and relerr(out[k], so) < 1e-9 and vec_relerr(grad[k], sg) < 1e-8
+    # config 5's real shape, 4 chains = 20 blocks of n = 4096 (2048-wide outer panels): chain 0 is the reference golden
+    g = golden("sep_sim_N4096_M5")
+    ctx.set_data(g["x"], g["Y"])
+    pars = np.stack([sim.perturb(g["pars"], 0.01 * k, 0.4 * k) for k in range(4)])
+    pars[0] = g["pars"]
+    out, grad, st = ctx.sep_batch_eval(pars, g["hyper"], bool(g["prior"]), True)
+    assert np.all(st == 0)
+    record_parity("sepbatch4_N4096_M5_chain0_vs_golden", neglog=(relerr(out[0][0], g["out"][0]), VAL_TOL), loglik=(relerr(out[0][1], g["out"][1]), 1e-8),
+                  grad=(vec_relerr(grad[0], g["grad"]), GRAD_TOL))
+    assert relerr(out[0][0], g["out"][0]) < VAL_TOL and relerr(out[0][1], g["out"][1]) < 1e-8 and vec_relerr(grad[0], g["grad"]) < GRAD_TOL
+    so, sg = ctx.logpos_sep(pars[3], g["hyper"], bool(g["prior"]), True)
+    assert relerr(out[3][1], so[1]) < 1e-10 and relerr(out[3], so) < 1e-9 and vec_relerr(grad[3], sg) < 1e-8
     # a chain whose covariance is numerically singular (the case of test_separable_and_stationary_objectives_recover_from_a_singular_
     # covariance: a zero row of B and sigma2 = 0) goes through the single-chain entry's jitter retries; the others are unaffected
     N, M = 96, 3
