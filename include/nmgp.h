@@ -178,8 +178,9 @@ int nmgp_logpos_sta(nmgp_ctx* ctx, const double* pars, const double hyper[5], in
  * wB_b[p] K_x,b + sigma2_b I join ONE batch of the blocked Cholesky (B M matrices of order N), as do the triangular products and the
  * inverse SYRK of the gradient; objective of logpos.py:216-296 per chain.
  * pars [B, 2N+T+1]; out6 [B, 6] (as nmgp_logpos_sep); grad [B, 2N+T+1] or NULL; status [B]: 0 = exact covariance, k in 1..3 = the
- * chain needed k jitter retries (re-evaluated through nmgp_logpos_sep: the reference's `while loglik != loglik` loop), another
- * positive code = numerical failure even so (its out6 row is NaN).  Returns 0 unless an API / runtime error occurred. */
+ * chain needed k jitter retries (re-evaluated through nmgp_logpos_sep: the reference's `while loglik != loglik` loop), negative =
+ * -(numerical failure code) if it failed even so (its out6 row is NaN, its gradient row zero).  Returns 0 unless an API / runtime
+ * error occurred. */
 int nmgp_sep_batch_eval(nmgp_ctx* ctx, const double* pars, int B, const double hyper[9], int prior, double* out6, double* grad,
                         int* status);
 

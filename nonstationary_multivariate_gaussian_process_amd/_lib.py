@@ -383,7 +383,7 @@ class Context:
 
     def sep_batch_eval(self, pars, hyper, prior=True, want_grad=False):
         """B chains of the separable model in one launch sequence: pars [B, 2N+T+1] -> (out [B, 6], grad [B, P] or None,
-        status [B]: 0 exact, 1..3 jitter retries needed, other positive = numerical failure (row NaN))."""
+        status [B]: 0 exact, 1..3 jitter retries needed, negative = numerical failure even so (row NaN))."""
         pars = as_f64(pars)
         P_ = 2 * self.N + self.T + 1
         if pars.ndim != 2 or pars.shape[1] != P_:

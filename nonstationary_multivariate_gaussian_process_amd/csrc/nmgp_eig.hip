@@ -568,7 +568,7 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
 // to chain-by-chain evaluation).  A chain whose covariance fails numerically is re-evaluated through nmgp_logpos_sep, i.e. with
 // the reference's jitter retries (status[b] = the retries it needed; negative-free: API errors fail the call).
 // pars [B, 2N+T+1]; out6 [B, 6]; grad [B, P] or NULL; status [B]: 0 exact, k > 0 evaluated with k jitter retries,
-// NMGP_NUM_NAN / a leading-minor index if even those failed (out6 row NaN).
+// negative = -(NMGP_NUM_NAN or the leading-minor index) if even those failed (out6 row NaN, gradient row zero).
 extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const double hyper[9], int prior, double* out6,
                                    double* grad, int* status) {
     if (!c) return NMGP_E_NULL;
@@ -585,7 +585,7 @@ extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const
         if (rc > 0) {
             for (int k = 0; k < 6; ++k) out6[(size_t)b * 6 + k] = std::nan("");
             if (want_grad) for (size_t k = 0; k < P; ++k) grad[(size_t)b * P + k] = 0.0;
-            status[b] = rc;
+            status[b] = -rc;                  // (negative: a leading-minor index must not read as a retry count)
         } else {
             status[b] = c->last_sep_attempts;
         }
@@ -803,7 +803,7 @@ extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const
         if (bad[b]) NMGP_TRY(one_by_one(b));
     c->last_sep_attempts = 0;
     for (int b = 0; b < B; ++b)
-        if (status[b] > 0 && status[b] <= NMGP_SEP_RETRIES && status[b] > c->last_sep_attempts) c->last_sep_attempts = status[b];
+        if (status[b] > c->last_sep_attempts) c->last_sep_attempts = status[b];
     return 0;
 }
 

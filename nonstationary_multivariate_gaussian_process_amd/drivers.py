@@ -541,7 +541,7 @@ class BatchedHMCSeparable(LockStepHMC):
         """U [B] and dU/dq [B, P]; a chain whose covariance stays numerically singular after the jitter retries gets U = inf."""
         out, g, status = self.ctx.sep_batch_eval(q, self.hyper, True, True)
         U = out[:, 0].copy()
-        bad = (status > 3) | ~np.isfinite(U)
+        bad = (status < 0) | ~np.isfinite(U)
         U[bad] = np.inf
         g[bad] = 0.0
         return U, g
