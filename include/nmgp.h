@@ -131,11 +131,27 @@ double* nmgp_svc_batch_grad_dev(nmgp_ctx* ctx);
  *   nmgp_svc_batch_traj_z     : like nmgp_svc_batch_traj, but z [B,P] in are STANDARD NORMALS: p0 = chol(M) z is formed on the
  *                               device (start kinetic energy = 1/2 |z|^2 for any metric) and kin1 [B] = 1/2 p1^T M^-1 p1 comes
  *                               back instead of p1 -- no [B,P] x [P,P] product is left on the host.
- * An API-level failure in the middle of a trajectory (either entry) restores the start state and requires a fresh value+gradient
- * evaluation + nmgp_svc_batch_traj_begin. */
+ *   nmgp_svc_batch_traj_set_mass_prior: the PRIOR-FACTOR metric (kind 3), the one that makes the sampler mix at N = 2048.  The posterior
+ *                               is dominated by the GP priors RBF(alpha, beta) + 1e-6 I on tilde_l and on each stride-T column of uL_vecs
+ *                               (logpos.py:357-365; condition number ~1e11), whose Cholesky factors the context caches; in the
+ *                               coordinates pars = mu + L_blk w, L_blk = blockdiag(chol Sigma_l, chol Sigma_L x T, 1), the Hessian of
+ *                               the potential is I + (a few dozen likelihood-informed directions).  M^-1 = L_blk (I + U diag(lam) U^T)^-1
+ *                               L_blk^T with U [S, r, P] (per subject: r orthonormal rows of length P), lam [S, r] >= 0 the rank-r
+ *                               correction (rank 0 / NULL: the pure prior metric); hyper as for the objective.  The device carries the
+ *                               whitened momentum L_blk^T p: every leapfrog step costs two triangular mat-vecs with the cached
+ *                               factors and two [P, r] products per chain, no solve and no [P, P] matrix.  Only nmgp_svc_batch_traj_z
+ *                               runs under this metric.  nmgp_svc_batch_set_subjects* resets it to the identity (it belongs to the
+ *                               subjects it was built for).
+ *   nmgp_svc_batch_prior_apply: out [B,P] = L_blk in (trans 0) or L_blk^T in (trans 1) for B parameter-shaped host vectors -- the
+ *                               change of coordinates of that metric, exported so that the caller can build U, lam (Hessian-vector
+ *                               products of the likelihood in whitened coordinates: drivers.prior_lowrank_metric).
+ * An API-level failure anywhere in a trajectory call (either entry; inside the leapfrog loop or in the end point's reductions and
+ * copies) restores the start state and requires a fresh value+gradient evaluation + nmgp_svc_batch_traj_begin. */
 int nmgp_svc_batch_traj_begin(nmgp_ctx* ctx);
 int nmgp_svc_batch_traj_set_mass(nmgp_ctx* ctx, int kind, const double* minv);
 int nmgp_svc_batch_traj_set_mass_chol(nmgp_ctx* ctx, int kind, const double* mchol);
+int nmgp_svc_batch_traj_set_mass_prior(nmgp_ctx* ctx, const double hyper[8], int rank, const double* U, const double* lam);
+int nmgp_svc_batch_prior_apply(nmgp_ctx* ctx, const double hyper[8], int trans, const double* in, double* out);
 int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
                         double* q1, double* p1, double* U1, int* failed);
 int nmgp_svc_batch_traj_z(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* z,

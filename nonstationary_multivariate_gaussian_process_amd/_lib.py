@@ -55,6 +55,8 @@ SIGNATURES = {
     "nmgp_svc_batch_traj_set_mass_chol": (I, [V, I, P]),
     "nmgp_svc_batch_traj_z": (I, [V, P, I, D, I, P, P, P, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
+    "nmgp_svc_batch_traj_set_mass_prior": (I, [V, P, I, P, P]),
+    "nmgp_svc_batch_prior_apply": (I, [V, P, I, P, P]),
     "nmgp_svc_batch_adam_begin": (I, [V]),
     "nmgp_svc_batch_adam_step": (I, [V, P, I, D, D, D, D, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_get_pars": (I, [V, P]),
@@ -306,6 +308,34 @@ class Context:
             self.check(self.lib.nmgp_svc_batch_traj_set_mass_chol(self.h, 2, ptr(mt)))
         else:
             raise ValueError("mchol must be [P] or [P, P] with P = %d" % P)
+
+    def svc_batch_traj_set_mass_prior(self, hyper, U=None, lam=None):
+        """The prior-factor metric M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T of the trajectories (nmgp.h): L_blk from the cached
+        GP-prior factors named by hyper [8]; U [r, P] (one subject) or [S, r, P], lam [r] / [S, r] >= 0 the optional low-rank
+        correction in whitened coordinates (drivers.prior_lowrank_metric builds it)."""
+        hyper = as_f64(hyper)
+        if U is None:
+            self.check(self.lib.nmgp_svc_batch_traj_set_mass_prior(self.h, ptr(hyper), 0, None, None))
+            return
+        U, lam = as_f64(U), as_f64(lam)
+        P_ = self.N * (1 + self.T) + 1
+        if U.ndim == 2:
+            U, lam = U[None], lam.reshape(1, -1)
+        if U.ndim != 3 or U.shape[2] != P_ or lam.shape != U.shape[:2]:
+            raise NmgpError("U must be [S, r, P=%d] with lam [S, r]; got %s, %s" % (P_, U.shape, lam.shape))
+        U, lam = np.ascontiguousarray(U), np.ascontiguousarray(lam)
+        self.check(self.lib.nmgp_svc_batch_traj_set_mass_prior(self.h, ptr(hyper), int(U.shape[1]), ptr(U), ptr(lam)))
+
+    def svc_batch_prior_apply(self, hyper, v, trans=False):
+        """L_blk v (trans=False) or L_blk^T v (trans=True) for B parameter-shaped vectors v [B, P]: the change of coordinates of the
+        prior-factor metric (L_blk = blockdiag of the GP-prior Cholesky factors, 1 for the noise parameter)."""
+        hyper, v = as_f64(hyper), as_f64(v)
+        P_ = self.N * (1 + self.T) + 1
+        if v.shape != (self.B, P_):
+            raise NmgpError("v must be [B=%d, P=%d], got %s" % (self.B, P_, v.shape))
+        out = np.empty_like(v)
+        self.check(self.lib.nmgp_svc_batch_prior_apply(self.h, ptr(hyper), int(bool(trans)), ptr(v), ptr(out)))
+        return out
 
     def svc_batch_traj_z(self, hyper, prior, eps, nsteps, z):
         """One leapfrog trajectory per chain with momenta p0 = chol(M) z formed on the device from the standard normals z [B, P]:

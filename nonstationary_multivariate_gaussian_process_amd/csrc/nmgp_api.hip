@@ -649,11 +649,25 @@ extern "C" int nmgp_logpos_svc(nmgp_ctx* c, const double* pars, const double hyp
 // MCMC runs many independent chains per subject; their factorisations have identical shapes, so every kernel of
 // the forward path takes the chain index as a grid dimension.  The 96 latency-bound 64-wide panel steps of the
 // Cholesky are then paid once per batch instead of once per chain, and the MFMA trailing updates fill the chip.
+// back to the identity metric: every buffer of a mass matrix released
+static void mass_reset(nmgp_ctx* c) {
+    double** ptrs[] = {&c->b_minv, &c->b_vel, &c->b_mchol, &c->b_mU, &c->b_mw, &c->b_mc};
+    for (double** p : ptrs) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    c->b_mass_kind = 0;
+    c->b_mrank = 0;
+    c->b_traj_ready = false;             // a trajectory begun under the old metric must be begun again
+}
+
 static void free_batch(nmgp_ctx* c) {
     double** ptrs[] = {&c->b_pars, &c->b_ell, &c->b_Lv, &c->b_S, &c->b_z, &c->b_R, &c->b_scal, &c->b_q,
                        &c->b_S2, &c->b_Sinv, &c->b_alpha, &c->b_part, &c->b_grad, &c->b_R2, &c->b_tr,
-                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel, &c->b_mchol, &c->b_kin};
+                       &c->b_mom, &c->b_q0, &c->b_g0, &c->b_am, &c->b_av, &c->b_minv, &c->b_vel, &c->b_mchol, &c->b_kin,
+                       &c->b_mU, &c->b_mw, &c->b_mc};
     c->b_mass_kind = 0;
+    c->b_mrank = 0;
     c->b_cps = 1;
     if (c->b_alive) hipFree(c->b_alive);
     c->b_alive = nullptr;
@@ -754,6 +768,7 @@ extern "C" int nmgp_svc_batch_set_subjects_chains(nmgp_ctx* c, const double* x, 
     // new data: the resident gradient and a trajectory begun on the old subjects no longer describe the batch
     c->b_traj_ready = false;
     c->b_last_grad = false;
+    if (c->b_mass_kind == 3) mass_reset(c);      // a prior-factor metric belongs to the subjects it was built for: back to identity
     return 0;
 }
 
@@ -1048,12 +1063,7 @@ extern "C" int nmgp_svc_batch_traj_set_mass(nmgp_ctx* c, int kind, const double*
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t P = (size_t)c->P_svc, B = c->batch;
-    if (c->b_minv) hipFree(c->b_minv);
-    if (c->b_vel) hipFree(c->b_vel);
-    if (c->b_mchol) hipFree(c->b_mchol);
-    c->b_minv = c->b_vel = c->b_mchol = nullptr;
-    c->b_mass_kind = 0;
-    c->b_traj_ready = false;             // a trajectory begun under the old metric must be begun again
+    mass_reset(c);
     if (kind == 0) return 0;
     const size_t nelem = kind == 1 ? P : P * P;
     NMGP_TRY(nmgp_dev_alloc(c, &c->b_minv, nelem));
@@ -1084,6 +1094,35 @@ extern "C" int nmgp_svc_batch_traj_set_mass_chol(nmgp_ctx* c, int kind, const do
     return 0;
 }
 
+// The cached GP-prior factors the prior-factor metric is made of (per subject in a multi-subject batch).  Looked up by
+// (alpha, beta) at every use: the cache is a vector that may have grown since -- pointers into it are not kept.
+static int metric_factors(nmgp_ctx* c, PriorFactor** pl, PriorFactor** pL) {
+    const double* h = c->b_mhyp;
+    if (c->b_multi) {
+        NMGP_TRY(get_batch_prior(c, h[0], h[1], pl));
+        NMGP_TRY(get_batch_prior(c, h[2], h[3], pL));
+        NMGP_TRY(get_batch_prior(c, h[0], h[1], pl));      // (re-resolved: the second call may have grown the cache)
+    } else {
+        NMGP_TRY(nmgp_get_prior(c, h[0], h[1], pl));
+        NMGP_TRY(nmgp_get_prior(c, h[2], h[3], pL));
+        NMGP_TRY(nmgp_get_prior(c, h[0], h[1], pl));
+    }
+    return 0;
+}
+
+// out[b] (op)= coef op(L_blk) in[b] for the whole batch (nmgp_metric.hip)
+static int metric_trmm(nmgp_ctx* c, bool trans, const double* in, double* out, double coef, int mode, const int* bad) {
+    PriorFactor *pl = nullptr, *pL = nullptr;
+    NMGP_TRY(metric_factors(c, &pl, &pL));
+    const int N = c->N;
+    const bool multi = c->b_multi;
+    prior_trmm(c->stream, trans, pl->L, pl->ld, multi ? (long long)pl->ld * N : 0, pL->L, pL->ld, multi ? (long long)pL->ld * N : 0,
+               in, out, N, c->T, c->P_svc, c->batch, multi ? c->b_cps : c->batch, coef, mode, bad);
+    return 0;
+}
+// (single subject: cps = batch makes every chain "subject 0" of the metric's per-subject tables)
+static inline int metric_cps(const nmgp_ctx* c) { return c->b_multi ? c->b_cps : c->batch; }
+
 // p -= c g (chains whose gradient is defined), then -- if drift -- q += eps M^-1 p
 static int traj_kick_drift(nmgp_ctx* c, double kick, double eps, int drift) {
     const int B = c->batch;
@@ -1093,6 +1132,20 @@ static int traj_kick_drift(nmgp_ctx* c, double kick, double eps, int drift) {
     if (c->b_mass_kind == 0) {
         hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, kick, eps, drift, P, B);
         return 0;
+    }
+    if (c->b_mass_kind == 3) {
+        // whitened momentum u = L_blk^T p:  u -= c L_blk^T g;  q += eps L_blk W u,  W = I - U diag(lam / (1 + lam)) U^T
+        NMGP_TRY(metric_trmm(c, true, c->b_grad, c->b_mom, kick, 2, bad));
+        if (!drift) return 0;
+        const double* v = c->b_mom;
+        const int r = c->b_mrank;
+        if (r > 0) {
+            const size_t Sr = (size_t)(B / metric_cps(c)) * r;
+            lowrank_proj(s, c->b_mU, c->b_mom, c->b_mc, P, r, B, metric_cps(c));
+            lowrank_apply(s, c->b_mU, c->b_mw + Sr, c->b_mc, c->b_mom, c->b_vel, P, r, B, metric_cps(c));
+            v = c->b_vel;
+        }
+        return metric_trmm(c, false, v, c->b_pars, eps, 1, nullptr);
     }
     hmc_kick_drift(s, c->b_mom, c->b_grad, c->b_pars, bad, kick, eps, 0, P, B);
     if (!drift) return 0;
@@ -1106,6 +1159,106 @@ static int traj_kick_drift(nmgp_ctx* c, double kick, double eps, int drift) {
         hmc_drift(s, c->b_pars, c->b_mom, nullptr, c->b_minv, eps, P, B);
     }
     return 0;
+}
+
+// An API-level failure anywhere in a trajectory call puts the start state back (positions, gradients, validity flags) and demands a
+// fresh value+gradient evaluation + nmgp_svc_batch_traj_begin; the first failure's message is kept.
+static int traj_abort(nmgp_ctx* c, int rc) {
+    const int B = c->batch;
+    const size_t bytes = (size_t)B * c->P_svc * sizeof(double);
+    hipStream_t s = c->stream;
+    const std::string msg = c->err;
+    hipMemcpyAsync(c->b_pars, c->b_q0, bytes, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(c->b_grad, c->b_g0, bytes, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(c->b_hmc, c->b_hmc + B, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s);
+    hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    c->b_last_grad = false;
+    c->b_traj_ready = false;
+    c->err = msg;
+    return rc;
+}
+
+// The prior-factor metric (kind 3; nmgp_metric.hip):  M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T  with L_blk the block diagonal of
+// the cached Cholesky factors of the GP priors named by hyper (logpos.py:357-365: RBF(alpha_tilde_l, beta_tilde_l) + 1e-6 I for
+// tilde_l, RBF(alpha_L, beta_L) + 1e-6 I for each stride-T column of uL_vecs, 1 for tilde_sigma2_err) and an optional rank-r
+// correction for the curvature the likelihood adds in the whitened coordinates.  U: [S, r, P] (subject s's orthonormal directions as
+// r rows of length P; S = number of subjects of the batch, 1 without nmgp_svc_batch_set_subjects), lam: [S, r] >= 0.  rank 0: the
+// pure prior metric (U, lam may be NULL).
+extern "C" int nmgp_svc_batch_traj_set_mass_prior(nmgp_ctx* c, const double hyper[8], int rank, const double* U, const double* lam) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper) return nmgp_fail(c, NMGP_E_NULL, "hyper must not be NULL");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    if (rank < 0 || rank > 1024) return nmgp_fail(c, NMGP_E_SHAPE, "rank of the metric's correction must be in [0, 1024]");
+    if (rank > 0 && (!U || !lam)) return nmgp_fail(c, NMGP_E_NULL, "U / lam must not be NULL for rank > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t P = (size_t)c->P_svc, B = c->batch;
+    const size_t S = c->b_multi ? B / c->b_cps : 1;
+    for (size_t k = 0; k < S * (size_t)rank; ++k)
+        if (!(lam[k] >= 0.0) || !std::isfinite(lam[k]))
+            return nmgp_fail(c, NMGP_E_SHAPE, "lam[%zu] = %g: the correction's eigenvalues must be finite and >= 0", k, lam[k]);
+    mass_reset(c);
+    c->b_mhyp[0] = hyper[1];
+    c->b_mhyp[1] = hyper[2];
+    c->b_mhyp[2] = hyper[4];
+    c->b_mhyp[3] = hyper[5];
+    c->b_mass_kind = 3;                          // (metric_factors reads b_mhyp)
+    PriorFactor *pl = nullptr, *pL = nullptr;
+    int rc = metric_factors(c, &pl, &pL);        // builds the factors now, so that a non-PD prior is reported here
+    if (rc == 0 && rank > 0) {
+        std::vector<double> w(3 * S * rank);
+        for (size_t k = 0; k < S * (size_t)rank; ++k) {
+            w[k] = std::sqrt(1.0 + lam[k]) - 1.0;
+            w[S * rank + k] = -lam[k] / (1.0 + lam[k]);
+            w[2 * S * rank + k] = lam[k] / (1.0 + lam[k]);
+        }
+        rc = nmgp_dev_alloc(c, &c->b_mU, S * rank * P);
+        if (rc == 0) rc = nmgp_dev_alloc(c, &c->b_mw, 3 * S * rank);
+        if (rc == 0) rc = nmgp_dev_alloc(c, &c->b_mc, B * rank);
+        if (rc == 0) rc = nmgp_dev_alloc(c, &c->b_vel, B * P);
+        if (rc == 0) {
+            hipError_t e = hipMemcpyAsync(c->b_mU, U, S * rank * P * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->b_mw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = nmgp_fail(c, NMGP_E_HIP, "upload of the metric's correction failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc != 0) {
+        const std::string msg = c->err;
+        mass_reset(c);
+        c->err = msg;
+        return rc;
+    }
+    c->b_mrank = rank;
+    return 0;
+}
+
+// out[b] = op(L_blk) in[b] for the B parameter-shaped vectors in [B, P] (host): trans = 0: L_blk v (whitened -> parameter
+// coordinates, without the prior mean), trans = 1: L_blk^T g (a gradient -> whitened coordinates).  L_blk as above, from hyper.
+extern "C" int nmgp_svc_batch_prior_apply(nmgp_ctx* c, const double hyper[8], int trans, const double* in, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper || !in || !out) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
+    if (c->batch <= 0) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_alloc must be called first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t P = (size_t)c->P_svc, B = c->batch;
+    double *din = nullptr, *dout = nullptr;
+    NMGP_TRY(nmgp_scratch_get(c, 3, B * P, &din));
+    NMGP_TRY(nmgp_scratch_get(c, 4, B * P, &dout));
+    HIP_TRY(c, hipMemcpyAsync(din, in, B * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // (the factors are looked up through b_mhyp: set it for the call, put the trajectory metric's back afterwards)
+    double keep[4];
+    std::memcpy(keep, c->b_mhyp, sizeof keep);
+    c->b_mhyp[0] = hyper[1];
+    c->b_mhyp[1] = hyper[2];
+    c->b_mhyp[2] = hyper[4];
+    c->b_mhyp[3] = hyper[5];
+    const int rc = metric_trmm(c, trans != 0, din, dout, 1.0, 0, nullptr);
+    std::memcpy(c->b_mhyp, keep, sizeof keep);
+    NMGP_TRY(rc);
+    HIP_TRY(c, hipMemcpyAsync(out, dout, B * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return nmgp_take_launch_error(c);
 }
 
 // The leapfrog loop shared by nmgp_svc_batch_traj / nmgp_svc_batch_traj_z: the momenta are in b_mom.  ANY API-level failure in
@@ -1132,19 +1285,30 @@ static int traj_run(nmgp_ctx* c, const double hyper[8], int prior, double eps, i
         const bool last = step == nsteps - 1;
         rc = traj_kick_drift(c, last ? 0.5 * eps : eps, eps, last ? 0 : 1);
     }
-    if (rc) {
-        const std::string msg = c->err;                  // keep the first failure's message
-        hipMemcpyAsync(c->b_pars, c->b_q0, bytes, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(c->b_grad, c->b_g0, bytes, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(bad, bad0, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s);
-        hipStreamSynchronize(s);
-        c->b_last_grad = false;
-        c->b_traj_ready = false;
-        c->err = msg;
-        return rc;
-    }
+    if (rc) return traj_abort(c, rc);
     return 0;
 }
+
+// failures AFTER the leapfrog loop (the end point's GEMM / reductions / copies) take the same exit as failures inside it
+#define TRAJ_HIP_TRY(ctx, expr)                                                                                            \
+    do {                                                                                                                   \
+        hipError_t e__ = (expr);                                                                                           \
+        if (e__ != hipSuccess)                                                                                             \
+            return traj_abort(ctx, nmgp_fail(ctx, NMGP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                                             __LINE__));                                                                   \
+    } while (0)
+#define TRAJ_BLAS_TRY(ctx, expr)                                                                                           \
+    do {                                                                                                                   \
+        rocblas_status s__ = (expr);                                                                                       \
+        if (s__ != rocblas_status_success)                                                                                 \
+            return traj_abort(ctx, nmgp_fail(ctx, NMGP_E_HIP, "%s failed: rocblas_status %d (%s:%d)", #expr, (int)s__, __FILE__, \
+                                             __LINE__));                                                                   \
+    } while (0)
+#define TRAJ_TRY(ctx, expr)                      \
+    do {                                         \
+        int r__ = (expr);                        \
+        if (r__ != 0) return traj_abort(ctx, r__); \
+    } while (0)
 
 // One trajectory for every chain: p0 [B, P] (host) are the momenta drawn by the caller; `nsteps` leapfrog steps of size `eps`
 // (mass matrix: nmgp_svc_batch_traj_set_mass, identity by default), one batched value+gradient evaluation per step.  Returns the end point q1, p1 [B, P], the
@@ -1156,6 +1320,9 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
     if (!hyper || !p0 || !q1 || !p1 || !U1 || !failed) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
     if (!c->b_traj_ready) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_begin must be called on the current state");
     if (nsteps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "nsteps must be positive");
+    if (c->b_mass_kind == 3)
+        return nmgp_fail(c, NMGP_E_STATE, "the prior-factor metric carries the whitened momentum L_blk^T p: use nmgp_svc_batch_traj_z "
+                         "(momenta drawn on the device)");
     HIP_TRY(c, hipSetDevice(c->device));
     const int B = c->batch;
     const long long P = c->P_svc;
@@ -1164,19 +1331,20 @@ extern "C" int nmgp_svc_batch_traj(nmgp_ctx* c, const double hyper[8], int prior
     HIP_TRY(c, hipMemcpyAsync(c->b_mom, p0, bytes, hipMemcpyHostToDevice, s));
     NMGP_TRY(traj_run(c, hyper, prior, eps, nsteps));
     std::vector<double> h((size_t)B * 16);
-    HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(p1, c->b_mom, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    NMGP_TRY(nmgp_take_launch_error(c));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(p1, c->b_mom, bytes, hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipStreamSynchronize(s));
+    TRAJ_TRY(c, nmgp_take_launch_error(c));
     for (int z = 0; z < B; ++z) U1[z] = failed[z] ? INFINITY : h[(size_t)z * 16 + 8];
     c->b_traj_ready = true;
     return 0;
 }
 
 // The same trajectory with the momenta DRAWN ON THE DEVICE: z [B, P] (host) are standard normals, p0 = chol(M) z (identity: p0 = z;
-// diagonal / dense: nmgp_svc_batch_traj_set_mass_chol must have uploaded chol(M) -- one GEMM [P, P] x [P, B] for all chains), so the
+// diagonal / dense: nmgp_svc_batch_traj_set_mass_chol must have uploaded chol(M) -- one GEMM [P, P] x [P, B] for all chains; prior-factor
+// metric: the whitened momentum u = (I + U diag(lam) U^T)^1/2 z), so the
 // start kinetic energy is 1/2 |z|^2 whatever the metric, and the END kinetic energy kin1 [B] = 1/2 p1^T M^-1 p1 comes back
 // instead of the momenta themselves (dense: one more GEMM; a reduction per chain).  This is what makes a dense-mass sample cost
 // what an identity-mass one does: the host's share was two [B, P] x [P, P] products per sample in NumPy (P = 14,337).
@@ -1186,7 +1354,7 @@ extern "C" int nmgp_svc_batch_traj_z(nmgp_ctx* c, const double hyper[8], int pri
     if (!hyper || !z || !q1 || !kin1 || !U1 || !failed) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
     if (!c->b_traj_ready) return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_begin must be called on the current state");
     if (nsteps <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "nsteps must be positive");
-    if (c->b_mass_kind != 0 && !c->b_mchol)
+    if ((c->b_mass_kind == 1 || c->b_mass_kind == 2) && !c->b_mchol)
         return nmgp_fail(c, NMGP_E_STATE, "nmgp_svc_batch_traj_set_mass_chol must upload chol(M) before momenta can be drawn on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     const int B = c->batch;
@@ -1194,6 +1362,8 @@ extern "C" int nmgp_svc_batch_traj_z(nmgp_ctx* c, const double hyper[8], int pri
     const size_t bytes = (size_t)B * P * sizeof(double);
     hipStream_t s = c->stream;
     const double one = 1.0, zero = 0.0;
+    const int r = c->b_mrank, mcps = metric_cps(c);
+    const size_t Sr = (size_t)(B / mcps) * r;
     if (!c->b_kin) NMGP_TRY(nmgp_dev_alloc(c, &c->b_kin, (size_t)B));
     if (c->b_mass_kind == 2) {
         // p0 [P x B] = chol(M) [P x P] z [P x B]   (z staged in the velocity buffer)
@@ -1203,22 +1373,30 @@ extern "C" int nmgp_svc_batch_traj_z(nmgp_ctx* c, const double hyper[8], int pri
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->b_mom, z, bytes, hipMemcpyHostToDevice, s));
         if (c->b_mass_kind == 1) hmc_scale(s, c->b_mom, c->b_mchol, P, B);
+        if (c->b_mass_kind == 3 && r > 0) {
+            // u = z + U ((sqrt(1 + lam) - 1) o U^T z)  ~  N(0, I + U diag(lam) U^T)
+            lowrank_proj(s, c->b_mU, c->b_mom, c->b_mc, P, r, B, mcps);
+            lowrank_apply(s, c->b_mU, c->b_mw, c->b_mc, c->b_mom, c->b_mom, P, r, B, mcps);
+        }
     }
     NMGP_TRY(traj_run(c, hyper, prior, eps, nsteps));
     if (c->b_mass_kind == 2) {
-        BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (int)P, B, (int)P, &one, c->b_minv,
-                                  (int)P, c->b_mom, (int)P, &zero, c->b_vel, (int)P));
+        TRAJ_BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, (int)P, B, (int)P, &one, c->b_minv,
+                                       (int)P, c->b_mom, (int)P, &zero, c->b_vel, (int)P));
         hmc_kinetic(s, c->b_mom, c->b_vel, nullptr, c->b_kin, P, B);
+    } else if (c->b_mass_kind == 3) {
+        lowrank_proj(s, c->b_mU, c->b_mom, c->b_mc, P, r, B, mcps);
+        metric_kinetic(s, c->b_mom, c->b_mc, c->b_mw ? c->b_mw + 2 * Sr : nullptr, c->b_kin, P, r, B, mcps);
     } else {
         hmc_kinetic(s, c->b_mom, nullptr, c->b_mass_kind == 1 ? c->b_minv : nullptr, c->b_kin, P, B);
     }
     std::vector<double> h((size_t)B * 16);
-    HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(kin1, c->b_kin, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    NMGP_TRY(nmgp_take_launch_error(c));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(q1, c->b_pars, bytes, hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(kin1, c->b_kin, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(h.data(), c->b_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipMemcpyAsync(failed, c->b_hmc + 2 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    TRAJ_HIP_TRY(c, hipStreamSynchronize(s));
+    TRAJ_TRY(c, nmgp_take_launch_error(c));
     for (int k = 0; k < B; ++k) U1[k] = failed[k] ? INFINITY : h[(size_t)k * 16 + 8];
     c->b_traj_ready = true;
     return 0;

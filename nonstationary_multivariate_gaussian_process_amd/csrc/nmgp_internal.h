@@ -140,11 +140,19 @@ struct nmgp_ctx {
     double* b_y = nullptr;      // [B, n] output-major
     std::vector<PriorFactor> b_priors;   // L: [B] x (ld x N), logdet: [B]
     int b_cps = 1;              // chains per subject of a multi-subject batch: batch element z belongs to subject z / b_cps
-    int b_mass_kind = 0;        // mass matrix of the device-resident trajectories: 0 identity, 1 diagonal, 2 dense (b_minv = M^-1)
+    int b_mass_kind = 0;        // mass matrix of the device-resident trajectories: 0 identity, 1 diagonal, 2 dense (b_minv = M^-1),
+                                // 3 prior-factor metric M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T (nmgp_metric.hip; b_mom then holds
+                                // the WHITENED momentum u = L_blk^T p)
     double* b_minv = nullptr;   // [P] or [P, P]
     double* b_vel = nullptr;    // [B, P] velocities M^-1 p (dense mass matrix)
     double* b_mchol = nullptr;  // chol(M): [P] (diagonal: sqrt) or [P, P] lower, column-major -- momenta p = chol(M) z drawn on the device
     double* b_kin = nullptr;    // [B] kinetic energies 1/2 p^T M^-1 p at the end of a trajectory
+    // prior-factor metric (kind 3): GP-prior hyper-parameters of the factors, rank-r likelihood correction per subject
+    double b_mhyp[4] = {0, 0, 0, 0};   // alpha_tilde_l, beta_tilde_l, alpha_L, beta_L
+    int b_mrank = 0;
+    double* b_mU = nullptr;     // [S, r, P]: subject s's orthonormal directions as r rows of length P
+    double* b_mw = nullptr;     // [3, S, r]: sqrt(1 + lam) - 1 (draw), -lam / (1 + lam) (velocity), lam / (1 + lam) (kinetic energy)
+    double* b_mc = nullptr;     // [B, r] projections U^T u
     int last_sep_attempts = 0;  // jitter retries the last separable / stationary evaluation needed (0 = the exact covariance)
     bool last_want_grad = false;
     int last_kind = 0;          // 1 svc
@@ -295,6 +303,14 @@ void hmc_scale(hipStream_t s, double* p, const double* d, long long P, int B);
 void hmc_kinetic(hipStream_t s, const double* p, const double* vel, const double* minv_diag, double* kin, long long P, int B);
 void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const double* g0, int* bad, const int* bad0,
                  const int* accept, long long P, int B);
+// ---- nmgp_metric.hip: the prior-factor metric of the trajectories ----
+// out[b] (op)= coef * op(L_blk) in[b] over the parameter layout (mode 0 assign, 1 out += coef acc, 2 out -= coef acc unless bad[b])
+void prior_trmm(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
+                const double* in, double* out, int N, int T, long long P, int B, int cps, double coef, int mode, const int* bad);
+void lowrank_proj(hipStream_t s, const double* U, const double* u, double* c, long long P, int r, int B, int cps);
+void lowrank_apply(hipStream_t s, const double* U, const double* wgt, const double* c, const double* in, double* out, long long P,
+                   int r, int B, int cps);
+void metric_kinetic(hipStream_t s, const double* u, const double* c, const double* sw, double* kin, long long P, int r, int B, int cps);
 int svc_adjoint(hipStream_t s, const double* x, const double* ell, const double* Lv, const double* alpha,
                 const double* Sinv, int ld, int N, int M, double* part, double ssign = 1.0, int batch = 1,
                 int xstride = 0, int cps = 1);

@@ -326,6 +326,134 @@ def sampler(**kw):
     return HMCSampler(**kw)
 
 
+SVC_HYPER_KEYS = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
+
+
+def polish_map(x, Y, hyper_pars, q, maxiter=500, ctx=None):
+    """A few L-BFGS iterations on the nonseparable objective from an Adam MAP estimate (the reference stops Adam after a fixed
+    number of iterations, Nonseparable_model.py:161-175; a sampler metric built from the Hessian wants a point that IS a mode).
+    Host-side SciPy driving single-chain value+gradient evaluations on the GPU.  Returns (pars, NegLog, gradient norm, evaluations)."""
+    from scipy.optimize import minimize
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    hyper = np.array([float(hyper_pars[k]) for k in SVC_HYPER_KEYS])
+    ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
+    n = [0]
+
+    def f(p):
+        n[0] += 1
+        try:
+            out, g = ctx.logpos_svc(p, hyper, True, True)
+        except _lib.NmgpNumericalError:
+            return np.inf, np.zeros_like(p)
+        return float(out[0]), g
+    res = minimize(f, np.asarray(q, dtype=np.float64), jac=True, method="L-BFGS-B",
+                   options={"maxiter": int(maxiter), "maxfun": int(2 * maxiter), "gtol": 1e-8, "ftol": 1e-16, "maxcor": 30})
+    return res.x, float(res.fun), float(np.linalg.norm(res.jac)), n[0]
+
+
+class PriorMetric:
+    """The prior-factor metric of the device-resident trajectories (``nmgp_svc_batch_traj_set_mass_prior``, csrc/nmgp_metric.hip):
+
+        M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T,   L_blk = blockdiag(chol Sigma_l, chol Sigma_L per uL column, 1)
+
+    with the Cholesky factors of the GP priors of ``logpos.py:357-365`` (cached on the device per subject) and an optional rank-r
+    correction ``U`` [r, P] (or [S, r, P] for S subjects; orthonormal rows), ``lam`` [r] / [S, r] >= 0 for the curvature the
+    likelihood adds in the whitened coordinates ``pars = mu + L_blk w`` -- see :func:`prior_lowrank_metric`.  It takes the place of
+    the ``M = inv(sample covariance)`` the reference's production runs pass (Nonseparable_model_mpiKAISER.py:398-411), which at
+    P = 14,337 would need more draws than a run has."""
+
+    def __init__(self, hyper_pars, U=None, lam=None, info=None):
+        self.hyper = np.array([float(hyper_pars[k]) for k in SVC_HYPER_KEYS])
+        self.U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
+        self.lam = None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)
+        self.info = info or {}
+
+    @property
+    def rank(self):
+        return 0 if self.U is None else int(self.U.shape[-2])
+
+
+def prior_lowrank_metric(x, Y, hyper_pars, q_ref, rank=96, oversample=32, power_iters=1, h=1e-3, lam_min=0.5, seed=0, ctx=None,
+                         batch=None):
+    """Build the :class:`PriorMetric` of ONE subject at ``q_ref`` (its MAP estimate): the top eigenpairs of
+
+        A = L_blk^T  Hess(-loglik)(q_ref)  L_blk        (the prior's own Hessian is the identity in these coordinates)
+
+    by randomised subspace iteration (``rank + oversample`` probe vectors, ``power_iters`` extra passes).  Every Hessian-vector
+    product is a central difference of the LIKELIHOOD gradient (``Prior=False``: no ill-conditioned prior solve enters), ``batch``
+    of them per batched launch sequence (``nmgp_svc_batch_eval``), the change of coordinates runs on the device
+    (``nmgp_svc_batch_prior_apply``).  ``h``: largest parameter displacement of a probe.  Eigenvalues with |lam| below ``lam_min``
+    are dropped (they change a direction's scale by < 25 %); a negative one beyond that enters as |lam|.  Cost: (2 + power_iters) x 2 x (rank + oversample) gradient evaluations."""
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    hyper = np.array([float(hyper_pars[k]) for k in SVC_HYPER_KEYS])
+    q_ref = np.asarray(q_ref, dtype=np.float64).reshape(-1)
+    P = q_ref.shape[0]
+    k = int(min(rank + oversample, P))
+    B = int(batch) if batch else min(k, 128)
+    ctx.set_data(x, Y)
+    ctx.svc_batch_alloc(B)
+    n_grad = [0]
+
+    def in_chunks(V, fn):
+        out = np.empty_like(V)
+        buf = np.zeros((B, P))
+        for a in range(0, V.shape[0], B):
+            m = min(B, V.shape[0] - a)
+            buf[:m] = V[a:a + m]
+            buf[m:] = buf[0]                  # pad with a valid row
+            out[a:a + m] = fn(buf)[:m]
+        return out
+
+    def lik_grad(Q):
+        ctx.svc_batch_set_pars(Q)
+        ctx.svc_batch_eval(hyper, False, want_grad=True)
+        out, status = ctx.svc_batch_fetch()
+        if not valid_rows(out, status).all():
+            raise RuntimeError("prior_lowrank_metric: the likelihood is undefined at a probe point (status %s): reduce h" % status)
+        n_grad[0] += Q.shape[0]
+        return ctx.svc_batch_fetch_grad()
+
+    def hvp(V):
+        """A V^T for the rows of V [k, P]."""
+        D = in_chunks(V, lambda v: ctx.svc_batch_prior_apply(hyper, v, trans=False))
+        t = h / np.maximum(np.abs(D).max(1), 1e-300)
+        Gp = in_chunks(q_ref[None] + t[:, None] * D, lik_grad)
+        Gm = in_chunks(q_ref[None] - t[:, None] * D, lik_grad)
+        Hq = (Gp - Gm) / (2.0 * t[:, None])
+        return in_chunks(Hq, lambda g: ctx.svc_batch_prior_apply(hyper, g, trans=True))
+
+    def orth(Yv):
+        Q, _ = np.linalg.qr(Yv.T)
+        return np.ascontiguousarray(Q.T)
+
+    rng = np.random.default_rng(seed)
+    Yv = hvp(rng.standard_normal((k, P)))
+    for _ in range(int(power_iters)):
+        Yv = hvp(orth(Yv))
+    Q = orth(Yv)
+    AQ = hvp(Q)
+    Tm = AQ @ Q.T
+    asym = float(np.abs(Tm - Tm.T).max() / max(np.abs(Tm).max(), 1e-300))
+    ev, W = np.linalg.eigh(0.5 * (Tm + Tm.T))
+    # Largest |eigenvalue| first.  A NEGATIVE eigenvalue below -lam_min means q_ref is not a mode along that direction (an
+    # unconverged MAP estimate, a saddle): the metric takes |lam| there (the SoftAbs rule), which keeps the leapfrog step stable
+    # while the chain leaves the region; the direction's true scale is then found by the sampler, not by the metric.
+    order = np.argsort(-np.abs(ev))
+    ev, W = ev[order], W[:, order]
+    keep = np.flatnonzero(np.abs(ev[:rank]) > lam_min)
+    U = np.ascontiguousarray(W[:, keep].T @ Q)
+    lam = np.ascontiguousarray(np.abs(ev[keep]))
+    info = {"probes": k, "power_iters": int(power_iters), "h": float(h), "grad_evals": int(n_grad[0]), "kept": int(keep.size),
+            "lam_max": float(lam[0]) if keep.size else 0.0, "lam_min_kept": float(lam[-1]) if keep.size else 0.0,
+            "first_dropped": float(ev[keep.size]) if keep.size < ev.size else None,
+            "negative_kept": [float(v) for v in ev[keep] if v < 0], "most_negative": float(ev.min()),
+            "asymmetry_of_projected_hessian": asym, "eigenvalues": [float(v) for v in ev[:min(ev.size, rank + 8)]]}
+    return PriorMetric(hyper_pars, U if keep.size else None, lam if keep.size else None, info)
+
+
 class LockStepHMC:
     """B independent HMC chains advanced in lock-step: every leapfrog step asks ``potential_and_grad(q [B, P])`` for the
     potentials U [B] and gradients [B, P] of ALL chains at once (U = inf marks a chain whose potential is undefined at
@@ -351,8 +479,13 @@ class LockStepHMC:
         chol(M) z, the kinetic energy is 1/2 p^T M^-1 p and the drift q += eps M^-1 p."""
         P = self.P
         self.mass_kind = 0
-        self.Mchol = self.Minv = None
+        self.Mchol = self.Minv = self.metric = None
         if M is None and Minv is None:
+            return
+        if isinstance(M, PriorMetric):
+            # the prior-factor metric lives on the device only (whitened momenta, cached prior factors): BatchedHMC's resident loop
+            self.mass_kind = 3
+            self.metric = M
             return
         if M is None:
             Minv = np.asarray(Minv, dtype=np.float64)
@@ -376,11 +509,15 @@ class LockStepHMC:
         z = np.stack([r.standard_normal(self.P) for r in self.rngs])
         if self.mass_kind == 0:
             return z
+        if self.mass_kind == 3:
+            raise NotImplementedError("a PriorMetric runs in BatchedHMC's device-resident loop only")
         return z * self.Mchol if self.mass_kind == 1 else z @ self.Mchol.T
 
     def velocity(self, p):
         if self.mass_kind == 0:
             return p
+        if self.mass_kind == 3:
+            raise NotImplementedError("a PriorMetric runs in BatchedHMC's device-resident loop only")
         return p * self.Minv if self.mass_kind == 1 else p @ self.Minv          # (M^-1 is symmetric)
 
     def kinetic(self, p):
@@ -451,9 +588,11 @@ class BatchedHMC(LockStepHMC):
         # host's share of a dense-mass sample was two [B, P] x [P, P] NumPy products -- off for the identity (where it would only
         # change the summation order of 1/2 |p|^2 against the host-side loop the tests compare with bit for bit).
         self.device_momenta = (self.mass_kind != 0) if device_momenta is None else bool(device_momenta)
+        if self.mass_kind == 3:
+            if not self.device_resident or not self.device_momenta:
+                raise ValueError("a PriorMetric needs device_resident=True and device_momenta=True")
         self.ctx = ctx if ctx is not None else _lib.default_context()
-        keys = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
-        self.hyper = np.array([float(hyper_pars[k]) for k in keys])
+        self.hyper = np.array([float(hyper_pars[k]) for k in SVC_HYPER_KEYS])
         x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
         if x.ndim == 2:
             # one chain per SUBJECT (BASELINE config 4's unit: x [B, N], Y [B, N, M], every subject with its own prior factors)
@@ -486,25 +625,36 @@ class BatchedHMC(LockStepHMC):
         the same random streams as the host-side lock-step loop (``device_resident=False``), bit for bit."""
         if not self.device_resident:
             return super().run(sample_size)
+        import time
         B, P = self.B, self.P
         samples = np.zeros((sample_size, B, P))
+        t_start = time.perf_counter()
         U, _ = self.potential_and_grad(self.q)           # leaves q and dU/dq resident
-        self.ctx.svc_batch_traj_set_mass(None if self.mass_kind == 0 else self.Minv)
-        if self.device_momenta and self.mass_kind != 0:
-            self.ctx.svc_batch_traj_set_mass_chol(self.Mchol)
+        if self.mass_kind == 3:
+            self.ctx.svc_batch_traj_set_mass_prior(self.metric.hyper, self.metric.U, self.metric.lam)
+        else:
+            self.ctx.svc_batch_traj_set_mass(None if self.mass_kind == 0 else self.Minv)
+            if self.device_momenta and self.mass_kind != 0:
+                self.ctx.svc_batch_traj_set_mass_chol(self.Mchol)
         self.ctx.svc_batch_traj_begin()
         accepted = np.zeros(B)
         energy_err = np.zeros((sample_size, B))
+        t_loop = time.perf_counter()
+        t_traj = 0.0
         for it in range(sample_size):
             if self.device_momenta:
                 # the same random stream: chain b draws its P standard normals, then (below) the accept uniform
                 z = np.stack([r.standard_normal(P) for r in self.rngs])
                 H0 = U + 0.5 * (z * z).sum(1)            # p0 = chol(M) z  =>  1/2 p0^T M^-1 p0 = 1/2 |z|^2
+                t0 = time.perf_counter()
                 q1, K1, U1, failed = self.ctx.svc_batch_traj_z(self.hyper, True, self.eps, self.L, z)
+                t_traj += time.perf_counter() - t0
             else:
                 p0 = self.draw_momenta()
                 H0 = U + self.kinetic(p0)
+                t0 = time.perf_counter()
                 q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
+                t_traj += time.perf_counter() - t0
                 K1 = self.kinetic(p1)
             U1 = np.where(failed, np.inf, U1)
             H1 = U1 + K1
@@ -518,7 +668,12 @@ class BatchedHMC(LockStepHMC):
             accepted += acc
             energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
             samples[it] = self.q
-        return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
+        t_end = time.perf_counter()
+        # where a sample's wall time goes: the synchronous trajectory calls (upload of the normals, the leapfrog launches, the end
+        # point's download) against everything the host does around them (normal draws, energies, accept test, bookkeeping)
+        timing = {"setup_seconds": t_loop - t_start, "loop_seconds": t_end - t_loop, "trajectory_call_seconds": t_traj,
+                  "device_share": t_traj / max(t_end - t_loop, 1e-12)}
+        return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err, "timing": timing}
 
 
 class BatchedHMCSeparable(LockStepHMC):

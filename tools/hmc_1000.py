@@ -1,18 +1,21 @@
 """BASELINE config 3 as worded: the nonseparable GP at N = 2048, D = 3 on one MI355X, 1000 MCMC iterations.
 
-    python tools/hmc_1000.py [--chains 8] [--iters 1000] [--pilot 100] [--mass diag|identity] [--step auto|<eps>]
-                             [--out gpurun_out/hmc_1000.json] [--progress gpurun_out/hmc_1000.progress]
+    python tools/hmc_1000.py [--chains 8] [--iters 1000] [--mass prior|diag|identity] [--rank 96] [--pilot 100]
+                             [--step auto|<eps>] [--out gpurun_out/hmc_1000.json] [--progress gpurun_out/hmc_1000.progress]
 
 The sampler call of Nonseparable_model.py:228-231 (HMC, 20 leapfrog steps per iteration, started from the MAP estimate,
 duplicate_samples=True) run for `--chains` chains of the bench subject in lock-step (drivers.BatchedHMC: trajectories resident in
 HBM, one batched value+gradient launch sequence per leapfrog step).  The reference's production runs pass a mass matrix derived
-from a previous run (Nonseparable_model_mpiKAISER.py:398-411); here: `--pilot` identity-mass iterations from the MAP point give a
-per-parameter scale, M = diag(1 / var) (momenta and energies on the device, nmgp_svc_batch_traj_z).  The step size is chosen by a
-short search for ~0.8 acceptance (`--step auto`; the reference's 1e-4 is rejected every time at this size: profiles/r03_hmc_steps.txt).
+from a previous run (Nonseparable_model_mpiKAISER.py:398-411).  `--mass prior` (default): the prior-factor metric
+M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T (drivers.PriorMetric; csrc/nmgp_metric.hip) -- the cached GP-prior Cholesky factors
+plus a rank-`--rank` correction for the likelihood's curvature found by randomised Hessian-vector products at the MAP point
+(drivers.prior_lowrank_metric, a few seconds); `--mass diag`: `--pilot` identity-mass iterations give a per-parameter scale,
+M = diag(1 / var) (round 4: does not mix).  The step size is chosen by a short search for ~0.8 acceptance (`--step auto`; the
+reference's 1e-4 is rejected every time at this size under the identity: profiles/r03_hmc_steps.txt).
 
-Writes one JSON document: acceptance, quantiles of |dH|, samples/s and gradient evaluations/s of the main run, effective sample
-size (per chain, summed over chains; Geyer's initial positive sequence on the FFT autocorrelation) and split-R-hat per parameter
-block (l~(x), the T columns of uL(x), log sigma^2), the posterior mean of l~(x) against the generating curve and the MAP estimate,
+Writes one JSON document: acceptance, quantiles of |dH|, samples/s and gradient evaluations/s of the main run, the MULTI-CHAIN
+effective sample size (rank-normalised split chains, between-chain variance in the denominator: Vehtari et al. 2021 -- chains that
+have not mixed get a small ESS, unlike a sum of per-chain figures), ESS per second, and split-R-hat per parameter block (l~(x), the T columns of uL(x), log sigma^2), the posterior mean of l~(x) against the generating curve and the MAP estimate,
 and the rms distance the chains travelled."""
 import argparse
 import json
@@ -58,6 +61,40 @@ def split_rhat(x):
     return np.sqrt(((h - 1) / h * W + Bv / h) / W)
 
 
+def multichain_ess(x, rank_normalize=True):
+    """x [S, C, K] -> bulk ESS [K] of the C chains TOGETHER (Stan's estimator: split chains, rank-normalised draws, autocorrelation
+    rho_t = 1 - (W - mean_c acov_t) / var_plus with the between-chain variance inside var_plus, Geyer's initial monotone positive
+    sequence).  Chains stuck at different places give var_plus >> W, rho_t ~ 1 and an ESS of a handful."""
+    from scipy.stats import norm, rankdata
+    S = x.shape[0] // 2 * 2
+    n = S // 2
+    y = np.concatenate([x[:n], x[n:S]], axis=1)             # [n, m, K]
+    m, K = y.shape[1], y.shape[2]
+    if rank_normalize:
+        r = rankdata(y.reshape(n * m, K), axis=0)
+        y = norm.ppf((r - 0.375) / (n * m + 0.25)).reshape(n, m, K)
+    yc = y - y.mean(0, keepdims=True)
+    nfft = 1 << (2 * n - 1).bit_length()
+    f = np.fft.rfft(yc, n=nfft, axis=0)
+    acov = np.fft.irfft(f * np.conj(f), n=nfft, axis=0)[:n] / n          # biased autocovariance per chain
+    chain_var = acov[0] * n / (n - 1.0)
+    W = chain_var.mean(0)
+    var_plus = W * (n - 1.0) / n
+    if m > 1:
+        var_plus = var_plus + y.mean(0).var(0, ddof=1)
+    var_plus = np.where(var_plus <= 0, np.inf, var_plus)
+    rho = 1.0 - (W[None] - acov.mean(1)) / var_plus[None]                # [n, K]
+    rho[0] = 1.0
+    npair = n // 2
+    pairs = rho[0:2 * npair:2] + rho[1:2 * npair:2]                      # [npair, K]
+    pos = np.cumprod(pairs > 0, axis=0).astype(bool)
+    pairs = np.where(pos, pairs, 0.0)
+    pairs = np.minimum.accumulate(pairs, axis=0)                         # initial monotone sequence
+    tau = -1.0 + 2.0 * pairs.sum(0)
+    tau = np.maximum(tau, 1.0 / np.log10(max(n * m, 10)))
+    return n * m / tau
+
+
 def block_stats(v):
     v = np.asarray(v, dtype=np.float64)
     v = v[np.isfinite(v)]
@@ -71,7 +108,10 @@ def main():
     ap.add_argument("--chains", type=int, default=8)
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--pilot", type=int, default=100)
-    ap.add_argument("--mass", choices=["diag", "identity"], default="diag")
+    ap.add_argument("--mass", choices=["prior", "diag", "identity"], default="prior")
+    ap.add_argument("--rank", type=int, default=96)
+    ap.add_argument("--probe-h", type=float, default=1e-3)
+    ap.add_argument("--polish", type=int, default=300, help="L-BFGS iterations on the committed Adam MAP estimate before the metric is built (0 = none)")
     ap.add_argument("--step", default="auto")
     ap.add_argument("--leap", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hmc_1000.json"))
@@ -98,7 +138,28 @@ def main():
            "reference_call": "Nonseparable_model.py:228-231 (step_size 1e-4, num_steps_in_leap 20, identity mass)"}
     eps_id = 4e-5
     mass_kw = {}
-    if a.mass == "diag":
+    if a.mass == "prior":
+        if a.polish > 0:
+            t0 = time.time()
+            qp, nl, gn, nev = drivers.polish_map(d["x"], d["Y"], sim.HYPER_SVC, qmap, maxiter=a.polish)
+            rec["map_polish"] = {"lbfgs_iterations_max": a.polish, "evaluations": nev, "seconds": time.time() - t0,
+                                 "log_posterior_before": float(g["target_value_hist"][-1]), "log_posterior_after": -nl,
+                                 "gradient_norm_after": gn, "rms_change_per_parameter": float(np.sqrt(np.mean((qp - qmap) ** 2)))}
+            note("polish: %d evaluations in %.1f s, log posterior %.4f -> %.4f, |grad| %.3g" % (
+                nev, time.time() - t0, float(g["target_value_hist"][-1]), -nl, gn))
+            qmap = qp
+            q0 = np.repeat(qmap[None], B, 0)
+        t0 = time.time()
+        met = drivers.prior_lowrank_metric(d["x"], d["Y"], sim.HYPER_SVC, qmap, rank=a.rank, oversample=32, power_iters=1, h=a.probe_h,
+                                           seed=7, batch=128)
+        dtm = time.time() - t0
+        rec["metric"] = dict(met.info, seconds=dtm, rank=met.rank)
+        mass_kw = {"M": met}
+        q_start = q0
+        note("metric: rank %d of %d probes in %.1f s (%d gradient evaluations), lam max %.3g, last kept %.3g, first dropped %s" % (
+            met.rank, met.info["probes"], dtm, met.info["grad_evals"], met.info["lam_max"], met.info["lam_min_kept"],
+            met.info["first_dropped"]))
+    elif a.mass == "diag":
         t0 = time.time()
         hp = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q0, step_size=eps_id, num_steps_in_leap=a.leap, seed=100)
         sp, ip = hp.run(a.pilot)
@@ -119,8 +180,12 @@ def main():
     if a.step == "auto":
         # diag mass: the drift per step is eps * scale_i * z_i, so eps is in units of the pilot's scales; start where the median
         # parameter moves as far per step as under the identity mass at eps_id
-        base = eps_id if a.mass == "identity" else eps_id / float(np.sqrt(np.median(mass_kw["Minv"])))
-        cands = [base * f for f in ((0.5, 1.0, 2.0) if a.mass == "identity" else (0.5, 1.0, 2.0, 4.0, 8.0, 16.0))]
+        if a.mass == "prior":
+            # whitened coordinates: the posterior is ~N(0, I) in P dimensions, so eps ~ P^-1/4; 20 steps of 0.08 = a quarter period
+            cands = [0.04, 0.06, 0.08, 0.11, 0.15]
+        else:
+            base = eps_id if a.mass == "identity" else eps_id / float(np.sqrt(np.median(mass_kw["Minv"])))
+            cands = [base * f for f in ((0.5, 1.0, 2.0) if a.mass == "identity" else (0.5, 1.0, 2.0, 4.0, 8.0, 16.0))]
         tried = []
         best = None
         for eps in cands:
@@ -139,17 +204,23 @@ def main():
     else:
         eps = float(a.step)
     rec["step_size"] = eps
-    rec["mass"] = ("diagonal, M = 1 / (mean squared displacement of the pilot), momenta and energies on the device (nmgp_svc_batch_traj_z)"
-                   if a.mass == "diag" else "identity")
+    rec["mass"] = {"diag": "diagonal, M = 1 / (mean squared displacement of the pilot), momenta and energies on the device (nmgp_svc_batch_traj_z)",
+                   "identity": "identity",
+                   "prior": "prior-factor metric M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T (nmgp_svc_batch_traj_set_mass_prior): cached "
+                            "GP-prior Cholesky factors + rank-%d likelihood correction, whitened momenta on the device" % (
+                                mass_kw["M"].rank if a.mass == "prior" else 0)}[a.mass]
     hm = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=1, **mass_kw)
     # run in segments so that progress is visible
     seg = 50
     chunks, accs, ees = [], [], []
     t0 = time.time()
     done = 0
+    t_traj = t_loop = 0.0
     while done < a.iters:
         k = min(seg, a.iters - done)
         s, info = hm.run(k)
+        t_traj += info["timing"]["trajectory_call_seconds"]
+        t_loop += info["timing"]["loop_seconds"]
         chunks.append(s)
         accs.append(info["accept_rate"] * k)
         ees.append(info["energy_error"])
@@ -163,7 +234,8 @@ def main():
     evals = (a.iters * a.leap + len(chunks)) * B
     rec["main"] = {"iterations": a.iters, "chains": B, "seconds": dt, "samples_per_s": a.iters * B / dt,
                    "grad_evals_per_s": evals / dt, "accept_rate_by_chain": acc.tolist(), "accept_rate_mean": float(acc.mean()),
-                   "abs_dH": block_stats(np.abs(ee)), "dH_mean": float(np.nanmean(ee))}
+                   "abs_dH": block_stats(np.abs(ee)), "dH_mean": float(np.nanmean(ee)),
+                   "device_share_of_the_sampling_loop": t_traj / max(t_loop, 1e-12)}
     # diagnostics on the second half (the first half as burn-in)
     Sb = S[a.iters // 2:]
     blocks = {"tilde_l": np.arange(N)}
@@ -171,13 +243,24 @@ def main():
         blocks["uL_col%d" % t] = N + np.arange(N) * T + t
     blocks["log_sigma2"] = np.array([P - 1])
     diag = {}
+    all_ess, all_rh = [], []
     for name, idx in blocks.items():
-        ess = autocorr_ess(Sb[:, :, idx])
+        ess = multichain_ess(Sb[:, :, idx])
         rh = split_rhat(Sb[:, :, idx])
-        diag[name] = {"ess": block_stats(ess), "split_rhat": block_stats(rh),
-                      "posterior_sd": block_stats(Sb[:, :, idx].reshape(-1, idx.size).std(0))}
-    rec["diagnostics_second_half"] = {"draws_per_chain": int(Sb.shape[0]), "chains": B, "blocks": diag,
-                                      "note": "ESS = sum over chains of S / tau (Geyer initial positive sequence); at most draws x chains"}
+        all_ess.append(ess)
+        all_rh.append(rh)
+        diag[name] = {"ess": block_stats(ess), "ess_per_chain_summed_r04_definition": block_stats(autocorr_ess(Sb[:, :, idx])),
+                      "split_rhat": block_stats(rh), "posterior_sd": block_stats(Sb[:, :, idx].reshape(-1, idx.size).std(0))}
+    all_ess, all_rh = np.concatenate(all_ess), np.concatenate(all_rh)
+    # the second half was produced in half the main run's time
+    rec["diagnostics_second_half"] = {
+        "draws_per_chain": int(Sb.shape[0]), "chains": B, "blocks": diag,
+        "all_parameters": {"ess": block_stats(all_ess), "split_rhat": block_stats(all_rh),
+                           "ess_per_second_median": float(np.median(all_ess) / (dt / 2)), "ess_per_second_min": float(all_ess.min() / (dt / 2)),
+                           "fraction_rhat_below_1.05": float(np.mean(all_rh < 1.05)), "fraction_rhat_below_1.2": float(np.mean(all_rh < 1.2))},
+        "note": "ESS = multi-chain bulk ESS (rank-normalised split chains, between-chain variance in var_plus; Vehtari et al. 2021): at "
+                "most ~draws x chains; chains that have not mixed get a small value.  The round-4 figure (sum of per-chain ESS) is kept "
+                "beside it for comparison only"}
     tl_true = d["pars_true"][:N]
     tl_mean = Sb[:, :, :N].mean((0, 1))
     rec["tilde_l_curve"] = {"rms_posterior_mean_minus_truth": float(np.sqrt(np.mean((tl_mean - tl_true) ** 2))),
