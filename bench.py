@@ -875,9 +875,30 @@ def self_launch(argv, n, script=None, out=None, timeout=None):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
     print("bench.py: --gpus %d without WORLD_SIZE: launching the ranks as a child process: %s" % (n, " ".join(cmd)),
           file=sys.stderr, flush=True)
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    # its own session = its own process group: on a timeout the whole group (launcher + ranks) is signalled, nothing else
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT, start_new_session=True)
     lines = []
-    try:
+
+    def stop_group():
+        import signal
+        for sig, grace in ((signal.SIGTERM, 20), (signal.SIGKILL, 20)):
+            try:
+                os.killpg(p.pid, sig)          # the group THIS call created (start_new_session): launcher and its workers
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=grace)
+                # the launcher is gone; its workers get the same signal through the group -- give them a moment, then make sure
+                time.sleep(0.5)
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+
+    def relay():
         for ln in p.stdout:
             is_rec = False
             if ln.startswith("{"):
@@ -889,10 +910,23 @@ def self_launch(argv, n, script=None, out=None, timeout=None):
                 lines.append(ln)
             else:
                 sys.stderr.write(ln)
+
+    # The child's stdout is read on a thread so that `timeout` bounds the WHOLE run: a rank that hangs (RCCL initialisation, a
+    # collective nobody joins) keeps the pipe open for ever, and a read loop on this thread would never reach the wait.
+    import threading
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    try:
         rc = p.wait(timeout=timeout)
+        reader.join(timeout=30)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the ranks did not finish within %s s: stopping the launcher child's process group (pgid %d)" % (timeout, p.pid),
+              file=sys.stderr, flush=True)
+        stop_group()
+        reader.join(timeout=30)
+        return 124
     except BaseException:
-        p.kill()            # the exact child we started; torch.distributed.run takes its workers down with it
-        p.wait()
+        stop_group()
         raise
     if rc != 0:
         print("bench.py: the torch.distributed.run child exited with %d (a rank failed)" % rc, file=sys.stderr, flush=True)

@@ -196,7 +196,12 @@ int nmgp_logpos_sta(nmgp_ctx* ctx, const double* pars, const double hyper[5], in
  * pars [B, 2N+T+1]; out6 [B, 6] (as nmgp_logpos_sep); grad [B, 2N+T+1] or NULL; status [B]: 0 = exact covariance, k in 1..3 = the
  * chain needed k jitter retries (re-evaluated through nmgp_logpos_sep: the reference's `while loglik != loglik` loop), negative =
  * -(numerical failure code) if it failed even so (its out6 row is NaN, its gradient row zero).  Returns 0 unless an API / runtime
- * error occurred. */
+ * error occurred.
+ * Every piece of the evaluation takes the chain as a grid dimension and the value and gradient halves are enqueued back to back: one
+ * host synchronisation per call.  Device workspace: B M (2N + 2) N doubles for the factorisation with gradients (N + 1 without) +
+ * B M N^2 (-S^-1) + 2 B N^2 (K_x, the weighted sum) -- 2.5 GB per chain at N = 4096, D = 5; the batch is evaluated in chunks of
+ * chains whose workspace stays below NMGP_SEP_BATCH_SLAB_GB (environment, default 96) and of at most 65,535 / M chains (grid limit);
+ * NMGP_E_SHAPE if a single chain does not fit.  Largest batch exercised on hardware: 32 chains x 5 blocks of N = 4096 (B M = 160). */
 int nmgp_sep_batch_eval(nmgp_ctx* ctx, const double* pars, int B, const double hyper[9], int prior, double* out6, double* grad,
                         int* status);
 

@@ -72,15 +72,22 @@ def _f(v):
 class _FusedObjective(torch.autograd.Function):
     """value + gradient of one of the three objectives from a single C-ABI call.
 
-    forward(kind, prior, hyper(list), Y, x, *param_pieces) -> tuple of 0-d tensors (first is the log posterior
-    ``res`` -- NOT negated -- the rest are the verbose components, marked non-differentiable)."""
+    forward(kind, (prior, grad_mode), hyper(list), Y, x, *param_pieces) -> tuple of 0-d tensors (first is the log posterior
+    ``res`` -- NOT negated -- the rest are the verbose components, marked non-differentiable).
+
+    The gradient is computed IN the forward call (one fused evaluation, ~3x the cost of the value alone at N = 2048) whenever a
+    parameter requires grad and autograd is recording at the call site (``grad_mode`` = ``torch.is_grad_enabled()`` there: inside
+    ``forward`` it is always off).  A caller that only reads the value of a tensor that requires grad -- the reference does so for
+    its deviance / verbose read-outs (Stationary_model.py:112,168) -- should wrap the call in ``with torch.no_grad():`` and pays
+    for the value only; the MAP loop (value, then ``backward()``: Nonseparable_model.py:169-171) gets both from the one call."""
 
     @staticmethod
-    def forward(fctx, kind, prior, hyper, Y, x, *pieces):
+    def forward(fctx, kind, flags, hyper, Y, x, *pieces):
+        prior, grad_mode = flags
         c = ctx()
         c.set_data(x, Y)
         flat = np.concatenate([to_np(p).reshape(-1) for p in pieces])
-        want_grad = any(isinstance(p, torch.Tensor) and p.requires_grad for p in pieces)
+        want_grad = bool(grad_mode) and any(isinstance(p, torch.Tensor) and p.requires_grad for p in pieces)
         try:
             if kind == "svc":
                 out, grad = c.logpos_svc(flat, hyper, prior, want_grad)
@@ -148,7 +155,7 @@ def logpos_SVC(tilde_l, uL_vecs, tilde_sigma2_err, Y, x, mu_tilde_l, alpha_tilde
     kernel #1 (Gibbs kernel x per-location L_i L_j^T, Kronecker placement, + sigma2 I), Cholesky, reductions,
     cached-factor GP priors, and -- when a parameter requires grad -- the analytic adjoint (kernel #5)."""
     hyper = [_f(mu_tilde_l), _f(alpha_tilde_l), _f(beta_tilde_l), _f(mu_L), _f(alpha_L), _f(beta_L), _f(a), _f(b)]
-    res = _FusedObjective.apply("svc", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(uL_vecs),
+    res = _FusedObjective.apply("svc", (bool(Prior), torch.is_grad_enabled()), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(uL_vecs),
                                 _as_tensor(tilde_sigma2_err))
     return res if verbose else res[0]
 
@@ -178,7 +185,7 @@ def logpos(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, alp
     ``_lib.Context.last_sep_attempts()``; only if every attempt fails is the result NaN."""
     hyper = [_f(mu_tilde_l), _f(alpha_tilde_l), _f(beta_tilde_l), _f(mu_tilde_sigma), _f(alpha_tilde_sigma),
              _f(beta_tilde_sigma), _f(a), _f(b), _f(c)]
-    res = _FusedObjective.apply("sep", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
+    res = _FusedObjective.apply("sep", (bool(Prior), torch.is_grad_enabled()), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
                                 _as_tensor(uL_vec), _as_tensor(tilde_sigma2_err))
     return res if verbose else res[0]
 
@@ -203,7 +210,7 @@ def logpos_S(tilde_l, tilde_sigma, uL_vec, tilde_sigma2_err, Y, x, mu_tilde_l, s
         # the reference leaves log_prior_tilde_l unbound in this combination (logpos.py:459)
         raise UnboundLocalError("local variable 'log_prior_tilde_l' referenced before assignment")
     hyper = [_f(mu_tilde_l), _f(sigma_tilde_l), _f(a), _f(b), _f(c)]
-    res = _FusedObjective.apply("sta", bool(Prior), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
+    res = _FusedObjective.apply("sta", (bool(Prior), torch.is_grad_enabled()), hyper, Y, x, _as_tensor(tilde_l), _as_tensor(tilde_sigma),
                                 _as_tensor(uL_vec), _as_tensor(tilde_sigma2_err))
     return res if verbose else res[0]
 

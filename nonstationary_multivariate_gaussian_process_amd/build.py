@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libnmgp_hip.so")
-SOURCES = ["nmgp_kernels.hip", "nmgp_kernels_eig.hip", "nmgp_chol.hip", "nmgp_trtri.hip", "nmgp_metric.hip", "nmgp_api.hip", "nmgp_eig.hip"]
+SOURCES = ["nmgp_kernels.hip", "nmgp_kernels_eig.hip", "nmgp_kernels_sep.hip", "nmgp_chol.hip", "nmgp_trtri.hip", "nmgp_metric.hip", "nmgp_api.hip", "nmgp_eig.hip"]
 ID_SOURCE = "nmgp_build_id.hip"        # compiled last, with -DNMGP_BUILD_ID="<tree id>"
 HEADERS = [os.path.join(INCLUDE, "nmgp.h"), os.path.join(CSRC, "nmgp_internal.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")

@@ -561,14 +561,245 @@ extern "C" int nmgp_logpos_sep(nmgp_ctx* c, const double* pars, const double hyp
 // The chains of the separable model's MCMC (the reference runs them one process each: Separable_model_mpisim.py:299-300;
 // every HMC iteration asks for the objective of logpos.py:216-296 once per leapfrog step) as ONE batch of the blocked Cholesky:
 // chain b contributes its M blocks S_bp = wB_b[p] K_x,b + sigma2_b I, so B chains are B M matrices of order N in every launch of
-// the factorisation, of the triangular matrix-vector product and of the inverse SYRK -- the launches that hold > 90 % of an
-// evaluation -- while the small per-chain pieces (M x M eigendecomposition on the host, covariance build, block assembly,
-// adjoint pass) are queued chain by chain on the same stream.  One chain's 5 blocks of N = 4096 are latency-bound (0.37 of the
-// FP64 matrix roofline); 16 chains are 80 matrices on the throughput schedule.  Cholesky formulation only (NMGP_SEP=eig falls back
-// to chain-by-chain evaluation).  A chain whose covariance fails numerically is re-evaluated through nmgp_logpos_sep, i.e. with
-// the reference's jitter retries (status[b] = the retries it needed; negative-free: API errors fail the call).
+// the factorisation, of the triangular matrix-vector product and of the inverse SYRK.  Since round 5 EVERY other piece takes the
+// chain as a grid dimension too (nmgp_kernels_sep.hip: parameter unpacking + rotation of y, the blocks written straight from
+// (x, ell, sigma) -- K_x itself only when the gradient needs it --, one pass over the blocks of -S^-1 for the traces and the weighted
+// sum, the fused adjoint; the M x M quadratic forms as strided-batched library products), and the whole evaluation -- value AND
+// gradient half -- is enqueued before the ONE synchronisation: the M x M eigendecompositions of B are host work done before the
+// first launch, nothing between the halves needs the host.  One chain's 5 blocks of N = 4096 are latency-bound (0.37 of the FP64
+// matrix roofline); 16 chains are 80 matrices on the throughput schedule.  Cholesky formulation only (NMGP_SEP=eig falls back to
+// chain-by-chain evaluation).  A chain whose covariance fails numerically is re-evaluated through nmgp_logpos_sep, i.e. with the
+// reference's jitter retries (status[b] = the retries it needed; API errors fail the call).
+// Memory: the batch is evaluated in chunks of chains whose device slab stays below NMGP_SEP_BATCH_SLAB_GB (default 96 GB:
+// 32 chains of N = 4096, D = 5 with gradients need 79 GB); grid dimensions bound a chunk to 65,535 / M chains.
 // pars [B, 2N+T+1]; out6 [B, 6]; grad [B, P] or NULL; status [B]: 0 exact, k > 0 evaluated with k jitter retries,
 // negative = -(NMGP_NUM_NAN or the leading-minor index) if even those failed (out6 row NaN, gradient row zero).
+namespace {
+
+struct SepBatchLayout {
+    size_t o_P, o_ell, o_sig, o_K, o_small, o_yt, o_z, o_alpha, o_red, o_info, o_R, o_R2, o_q, o_S;
+    size_t o_Cneg = 0, o_part = 0, o_C = 0, o_W = 0, o_Xi = 0, o_g = 0, o_tr = 0;
+    size_t total = 0, small_per = 0, tri_part = 0;
+    int ld = 0;
+    long long bs = 0;
+};
+
+SepBatchLayout sep_batch_layout(int B, int N, int M, int T, bool want_grad) {
+    SepBatchLayout L;
+    const size_t P = (size_t)2 * N + T + 1, NN = (size_t)N * N, BM = (size_t)B * M;
+    L.ld = want_grad ? (int)((((size_t)2 * N + 2 + 15) / 16) * 16) : (int)((((size_t)N + 1 + 15) / 16) * 16);
+    L.bs = (long long)L.ld * N;
+    L.small_per = (size_t)M + (size_t)M * M + 2;        // wB | VB (row-major) | sigma2 | pad
+    L.tri_part = (size_t)N * ((N + 255) / 256);
+    const size_t NJ = (N + 63) / 64;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 1) & ~(size_t)1; return o; };
+    L.o_P = take((size_t)B * P); L.o_ell = take((size_t)B * N); L.o_sig = take((size_t)B * N);
+    L.o_K = take(want_grad ? (size_t)B * NN : 2);       // K_x of every chain: only the gradient reads it back
+    L.o_small = take((size_t)B * L.small_per); L.o_yt = take(BM * N); L.o_z = take(BM * N);
+    L.o_alpha = take(BM * N); L.o_red = take(BM * 4); L.o_info = take(BM);
+    L.o_R = take((size_t)N * 2 * B); L.o_R2 = take((size_t)N * 2 * B); L.o_q = take((size_t)2 * B + 2);
+    L.o_S = take(BM * (size_t)L.bs);
+    if (want_grad) {
+        L.o_Cneg = take(BM * NN);
+        L.o_part = take(std::max(BM * L.tri_part, (size_t)B * NJ * N * 2 + 8));
+        L.o_C = take((size_t)B * NN);
+        L.o_W = take((size_t)B * N * M);
+        L.o_Xi = take((size_t)B * M * M);
+        L.o_g = take((size_t)B * 2 * N);
+        L.o_tr = take(BM * NMGP_SEP_TR_G * 3);
+    }
+    L.total = off;
+    return L;
+}
+
+// chains [0, B) of `pars` (already offset by the caller): everything enqueued, one synchronisation, host epilogue.  bad[b] = 1 marks a
+// chain whose blocks failed numerically (its out6 / grad rows are then unspecified: the caller re-evaluates it one by one).
+int sep_batch_core(nmgp_ctx* c, const double* pars, int B, const double hyper[9], int prior, double* out6, double* grad, int* status,
+                   std::vector<char>& bad) {
+    const int N = c->N, M = c->M, T = c->T;
+    const size_t P = (size_t)2 * N + T + 1;
+    const bool want_grad = grad != nullptr;
+    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_s = hyper[3], al_s = hyper[4], be_s = hyper[5];
+    const double a = hyper[6], bb = hyper[7], cc = hyper[8];
+    hipStream_t s = c->stream;
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
+    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
+    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));           // (re-resolved: the second call may have grown the cache)
+    const int BM = B * M;
+    const SepBatchLayout L = sep_batch_layout(B, N, M, T, want_grad);
+    const int xpad = (N + 1) & 1, xoff = N + 1 + xpad;
+    const int ld = L.ld;
+    const long long bs = L.bs;
+    const size_t NN = (size_t)N * N;
+    const int sp_ = (int)L.small_per;
+    const int G = NMGP_SEP_TR_G;
+    double* slab;
+    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, L.total, &slab));      // (the single-chain path's slot: the two never run at the same time)
+    double *dP = slab + L.o_P, *d_ell = slab + L.o_ell, *d_sig = slab + L.o_sig, *dK = slab + L.o_K, *d_small = slab + L.o_small;
+    double *yt = slab + L.o_yt, *z = slab + L.o_z, *alpha = slab + L.o_alpha, *red = slab + L.o_red;
+    int* info = reinterpret_cast<int*>(slab + L.o_info);
+    double *R = slab + L.o_R, *R2 = slab + L.o_R2, *dq = slab + L.o_q, *S = slab + L.o_S;
+    // ---- host: B = L L^T and its eigendecomposition, per chain (M x M: known before the first launch) ----
+    std::vector<EigWork> w(B);
+    std::vector<double> hsmall((size_t)B * L.small_per, 0.0), sig2(B), tse(B);
+    for (int b = 0; b < B; ++b) {
+        const double* pb = pars + (size_t)b * P;
+        tse[b] = pb[P - 1];
+        sig2[b] = std::exp(tse[b]);
+        build_B(pb + 2 * N, M, true, w[b].h_L, w[b].h_B);
+        jacobi_eigh(M, w[b].h_B.data(), w[b].h_wB, w[b].h_VB);
+        double* h = hsmall.data() + (size_t)b * L.small_per;
+        for (int p = 0; p < M; ++p) h[p] = w[b].h_wB[p];
+        for (int k = 0; k < M * M; ++k) h[M + k] = w[b].h_VB[k];
+        h[M + (size_t)M * M] = sig2[b];
+    }
+    HIP_TRY(c, hipMemcpyAsync(dP, pars, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(info, 0, (size_t)BM * sizeof(int), s));
+    PriorStreamScope pscope(c);
+    {
+        NmgpStage sp(c, NMGP_STAGE_COV);
+        sep_prep_b(s, dP, (long long)P, c->d_Y, d_small, sp_, N, M, d_ell, d_sig, yt, B);
+        sep_blocks_b(s, c->d_x, d_ell, d_sig, d_small, sp_, N, M, S, ld, bs, want_grad ? dK : nullptr, B);
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_CHOL);
+        set_row(s, S, ld, N, yt, N, BM, bs, N);
+        if (want_grad) identity_rows(s, S, ld, N + 1, N, xpad, BM, bs);
+        potrf_lower(s, c->stream2, nmgp_chol_events(c, N), S, ld, N, want_grad ? 1 + xpad : 1, want_grad ? N : 0, c->chol_nb1, info,
+                    BM, bs, 1, nmgp_syrk_hook(c));
+        get_row(s, S, ld, N, z, N, BM, bs, N);
+    }
+    {
+        NmgpStage sp(c, NMGP_STAGE_REDUCE);
+        chol_logdet_quad(s, S, ld, N, z, red, red + 1, BM, bs, 4);
+    }
+    {
+        // GP priors on tilde_l and tilde_sigma of every chain: 2 B right-hand sides against the cached factors
+        NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
+        two_col_rhs_b(pscope.sp, dP, (long long)P, mu_l, mu_s, N, R, B);
+        double* r2 = (want_grad && prior) ? R2 : nullptr;
+        if (pl == ps) {
+            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R, 2 * B, r2));
+        } else {
+            for (int b = 0; b < B; ++b) {
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R + (size_t)2 * b * N, 1, r2 ? r2 + (size_t)2 * b * N : nullptr));
+                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, R + (size_t)(2 * b + 1) * N, 1, r2 ? r2 + (size_t)(2 * b + 1) * N : nullptr));
+            }
+        }
+        col_sumsq(pscope.sp, R, N, N, 2 * B, dq);
+    }
+    pscope.done();
+    pscope.join();
+    std::vector<double> hr((size_t)BM * 4), hq((size_t)2 * B);
+    std::vector<int> hi(BM);
+    double hl[2];
+    HIP_TRY(c, hipMemcpyAsync(hr.data(), red, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)BM * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(hq.data(), dq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&hl[0], pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&hl[1], ps->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
+    // ---- gradient half: enqueued behind the value half without waiting for it (a chain that failed produces garbage here, which the
+    // epilogue discards) ----
+    std::vector<double> hx, hg, hR2, htr;
+    if (want_grad) {
+        double *Cneg = slab + L.o_Cneg, *part = slab + L.o_part, *C = slab + L.o_C, *W = slab + L.o_W, *Xi = slab + L.o_Xi, *d_g = slab + L.o_g;
+        double* trs = slab + L.o_tr;
+        const double one = 1.0, zero = 0.0;
+        {
+            NmgpStage sp(c, NMGP_STAGE_INVERSE);
+            tri_gemv_upper(s, S + xoff, ld, N, z, alpha, part, BM, bs, (long long)L.tri_part);
+            syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, BM, bs, (long long)NN, 1);              // -S_bp^-1
+        }
+        {
+            NmgpStage sp(c, NMGP_STAGE_ADJOINT);
+            sep_reduce_b(s, Cneg, dK, alpha, d_small, sp_, N, M, G, C, trs, B);
+            fill_lower_to_full(s, C, N, N, B);
+            sep_adjoint_b(s, c->d_x, d_ell, d_sig, alpha, d_small, sp_, M, C, N, part, d_g, B);
+            // Xi_b = alpha_b^T (K_b alpha_b): the M x M quadratic forms, strided-batched over the chains (W zeroed so that a
+            // beta = 0 implemented as a scaling cannot carry stale NaNs over)
+            HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)B * N * M * sizeof(double), s));
+            BLAS_TRY(c, rocblas_dsymm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, dK, N, (rocblas_stride)NN,
+                                                      alpha, N, (rocblas_stride)((size_t)M * N), &zero, W, N,
+                                                      (rocblas_stride)((size_t)M * N), B));
+            BLAS_TRY(c, rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, alpha, N,
+                                                      (rocblas_stride)((size_t)M * N), W, N, (rocblas_stride)((size_t)M * N), &zero, Xi, M,
+                                                      (rocblas_stride)((size_t)M * M), B));
+        }
+        hx.assign((size_t)B * M * M, 0.0);
+        hg.assign((size_t)B * 2 * N, 0.0);
+        hR2.assign((size_t)N * 2 * B, 0.0);
+        htr.assign((size_t)BM * G * 3, 0.0);
+        HIP_TRY(c, hipMemcpyAsync(hx.data(), Xi, hx.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(htr.data(), trs, htr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (prior) HIP_TRY(c, hipMemcpyAsync(hR2.data(), R2, hR2.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));          // the one synchronisation of the evaluation
+    NMGP_TRY(nmgp_take_launch_error(c));
+    // ---- host epilogue ----
+    for (int b = 0; b < B; ++b) {
+        bad[b] = 0;
+        double ll = 0.0;
+        for (int p = 0; p < M; ++p) {
+            if (hi[(size_t)b * M + p] != 0) bad[b] = 1;
+            ll += -0.5 * hr[((size_t)b * M + p) * 4] - 0.5 * hr[((size_t)b * M + p) * 4 + 1];
+        }
+        if (!std::isfinite(ll)) bad[b] = 1;
+        const double* pb = pars + (size_t)b * P;
+        const double lp_l = -0.5 * (N * LOG2PI + hq[(size_t)2 * b]) - hl[0];
+        const double lp_s = -0.5 * (N * LOG2PI + hq[(size_t)2 * b + 1]) - hl[1];
+        double lp_uL = 0.0;
+        std::vector<double> g_uL_prior(T, 0.0);
+        for (int t = 0; t < T; ++t) lp_uL += normal_logprob_f32(pb[2 * N + t], 0.0, cc, &g_uL_prior[t]);
+        const double lp_s2 = (-a - 1.0) * std::log(sig2[b]) - bb / sig2[b] + a * std::log(bb) - std::lgamma(a);
+        double res = ll;
+        if (prior) { res += lp_l; res += lp_s; res += lp_uL; res += lp_s2; res += tse[b]; }
+        double* o = out6 + (size_t)b * 6;
+        o[0] = -res; o[1] = ll; o[2] = lp_l; o[3] = lp_s; o[4] = lp_uL; o[5] = lp_s2;
+        status[b] = 0;
+        if (!want_grad || bad[b]) continue;
+        std::vector<double> tr(M, 0.0), tk(M, 0.0), aa(M, 0.0);
+        const double* tb = htr.data() + (size_t)b * M * G * 3;
+        for (int p = 0; p < M; ++p)
+            for (int g = 0; g < G; ++g) {
+                tr[p] += tb[((size_t)p * G + g) * 3];
+                tk[p] += tb[((size_t)p * G + g) * 3 + 1];
+                aa[p] += tb[((size_t)p * G + g) * 3 + 2];
+            }
+        // d loglik / dB = V_B Xi V_B^T,  Xi[p,p'] = 1/2 (alpha_p^T K alpha_p' - d_pp' <S_p^-1, K>)
+        std::vector<double> Xs((size_t)M * M), dB((size_t)M * M, 0.0), g_uL;
+        const double* hxb = hx.data() + (size_t)b * M * M;
+        for (int p = 0; p < M; ++p)
+            for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (hxb[(size_t)q * M + p] - (p == q ? tk[p] : 0.0));
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j) {
+                double acc = 0.0;
+                for (int p = 0; p < M; ++p)
+                    for (int q = 0; q < M; ++q) acc += w[b].h_VB[(size_t)i * M + p] * Xs[(size_t)p * M + q] * w[b].h_VB[(size_t)j * M + q];
+                dB[(size_t)i * M + j] = acc;
+            }
+        double ds = 0.0;
+        for (int p = 0; p < M; ++p) ds += 0.5 * (aa[p] - tr[p]);
+        dB_to_guL(dB, w[b].h_L, M, g_uL);
+        double* gb = grad + (size_t)b * P;
+        for (int i = 0; i < 2 * N; ++i) {
+            // (R2 holds the chain's two solved columns [tilde_l | tilde_sigma] back to back: the layout of the 2N leading parameters)
+            const double r = prior ? hR2[(size_t)2 * b * N + i] : 0.0;
+            gb[i] = -(hg[(size_t)b * 2 * N + i] - r);
+        }
+        for (int t = 0; t < T; ++t) gb[2 * N + t] = -(g_uL[t] + (prior ? g_uL_prior[t] : 0.0));
+        double ge = sig2[b] * ds;
+        if (prior) ge += (-a - 1.0) + bb / sig2[b] + 1.0;
+        gb[P - 1] = -ge;
+    }
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const double hyper[9], int prior, double* out6,
                                    double* grad, int* status) {
     if (!c) return NMGP_E_NULL;
@@ -595,209 +826,24 @@ extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const
         for (int b = 0; b < B; ++b) NMGP_TRY(one_by_one(b));
         return 0;
     }
-    const double mu_l = hyper[0], al_l = hyper[1], be_l = hyper[2], mu_s = hyper[3], al_s = hyper[4], be_s = hyper[5];
-    const double a = hyper[6], bb = hyper[7], cc = hyper[8];
-    hipStream_t s = c->stream;
     NMGP_TRY(ensure_eig_buffers(c, N));
-    PriorFactor *pl = nullptr, *ps = nullptr;
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
-    NMGP_TRY(nmgp_get_prior(c, al_s, be_s, &ps));
-    NMGP_TRY(nmgp_get_prior(c, al_l, be_l, &pl));
-    // ---- device memory: one slab, carved ----
-    const int BM = B * M;
-    const int xpad = (N + 1) & 1, xoff = N + 1 + xpad;
-    const int ld = want_grad ? (int)((((size_t)2 * N + 2 + 15) / 16) * 16) : (int)((((size_t)N + 1 + 15) / 16) * 16);
-    const long long bs = (long long)ld * N;
-    const size_t NN = (size_t)N * N;
-    const size_t small_per = (size_t)M + (size_t)M * M + 2;        // wB | VB (row-major) | sigma2 | pad
-    const int NJ = (N + 63) / 64;
-    const size_t tri_part = (size_t)N * ((N + 255) / 256);
-    const int G = NMGP_SEP_TR_G;                                    // partial sums per block that sep_traces leaves for the host
-    size_t off = 0;
-    auto take = [&](size_t n) { size_t o = off; off += (n + 1) & ~(size_t)1; return o; };
-    const size_t o_P = take((size_t)B * P), o_ell = take((size_t)B * N), o_sig = take((size_t)B * N), o_K = take((size_t)B * NN);
-    const size_t o_small = take((size_t)B * small_per), o_yt = take((size_t)BM * N), o_z = take((size_t)BM * N);
-    const size_t o_alpha = take((size_t)BM * N), o_red = take((size_t)BM * 4), o_info = take((size_t)BM);
-    const size_t o_R = take((size_t)N * 2 * B), o_R2 = take((size_t)N * 2 * B), o_q = take((size_t)2 * B + 2);
-    const size_t o_S = take((size_t)BM * bs);
-    size_t o_Cneg = 0, o_part = 0, o_C = 0, o_W = 0, o_Xi = 0, o_g = 0, o_tr = 0;
-    if (want_grad) {
-        o_Cneg = take((size_t)BM * NN);
-        o_part = take(std::max((size_t)BM * tri_part, (size_t)NJ * N * 2 + 8));
-        o_C = take(NN);
-        o_W = take((size_t)N * M);
-        o_Xi = take((size_t)B * M * M);
-        o_g = take((size_t)B * 2 * N);
-        o_tr = take((size_t)BM * G * 3);
-    }
-    double* slab;
-    NMGP_TRY(nmgp_scratch_get(c, SL_BIG, off, &slab));      // (the single-chain path's slot: the two never run at the same time)
-    double *dP = slab + o_P, *d_ell = slab + o_ell, *d_sig = slab + o_sig, *dK = slab + o_K, *d_small = slab + o_small;
-    double *yt = slab + o_yt, *z = slab + o_z, *alpha = slab + o_alpha, *red = slab + o_red;
-    int* info = reinterpret_cast<int*>(slab + o_info);
-    double *R = slab + o_R, *R2 = slab + o_R2, *dq = slab + o_q, *S = slab + o_S;
-    // ---- host: B, its eigendecomposition, per chain ----
-    std::vector<EigWork> w(B);
-    std::vector<double> hsmall((size_t)B * small_per, 0.0), sig2(B), tse(B);
-    for (int b = 0; b < B; ++b) {
-        const double* pb = pars + (size_t)b * P;
-        tse[b] = pb[P - 1];
-        sig2[b] = std::exp(tse[b]);
-        build_B(pb + 2 * N, M, true, w[b].h_L, w[b].h_B);
-        jacobi_eigh(M, w[b].h_B.data(), w[b].h_wB, w[b].h_VB);
-        double* h = hsmall.data() + (size_t)b * small_per;
-        for (int p = 0; p < M; ++p) h[p] = w[b].h_wB[p];
-        for (int k = 0; k < M * M; ++k) h[M + k] = w[b].h_VB[k];
-        h[M + (size_t)M * M] = sig2[b];
-    }
-    HIP_TRY(c, hipMemcpyAsync(dP, pars, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_small, hsmall.data(), hsmall.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemsetAsync(info, 0, (size_t)BM * sizeof(int), s));
-    PriorStreamScope pscope(c);
-    {
-        NmgpStage sp(c, NMGP_STAGE_COV);
-        for (int b = 0; b < B; ++b) {
-            const double* sm = d_small + (size_t)b * small_per;
-            exp_vec(s, dP + (size_t)b * P, N, d_ell + (size_t)b * N);
-            exp_vec(s, dP + (size_t)b * P + N, N, d_sig + (size_t)b * N);
-            gibbs_cov_sym(s, c->d_x, d_sig + (size_t)b * N, d_ell + (size_t)b * N, N, dK + (size_t)b * NN, N, false);
-            rotate_y(s, c->d_Y, sm + M, N, M, yt + (size_t)b * M * N);
-            sep_blocks(s, dK + (size_t)b * NN, sm, sm + M + (size_t)M * M, N, M, S + (size_t)b * M * bs, ld, bs);
-        }
-    }
-    {
-        NmgpStage sp(c, NMGP_STAGE_CHOL);
-        set_row(s, S, ld, N, yt, N, BM, bs, N);
-        if (want_grad) identity_rows(s, S, ld, N + 1, N, xpad, BM, bs);
-        potrf_lower(s, c->stream2, nmgp_chol_events(c, N), S, ld, N, want_grad ? 1 + xpad : 1, want_grad ? N : 0, c->chol_nb1, info,
-                    BM, bs, 1, nmgp_syrk_hook(c));
-        get_row(s, S, ld, N, z, N, BM, bs, N);
-    }
-    {
-        NmgpStage sp(c, NMGP_STAGE_REDUCE);
-        chol_logdet_quad(s, S, ld, N, z, red, red + 1, BM, bs, 4);
-    }
-    {
-        // GP priors on tilde_l and tilde_sigma of every chain: 2 B right-hand sides against the cached factors
-        NmgpStage sp(c, NMGP_STAGE_PRIOR, pscope.sp, 0.0, 0.0);
-        for (int b = 0; b < B; ++b)
-            two_col_rhs(pscope.sp, dP + (size_t)b * P, mu_l, dP + (size_t)b * P + N, mu_s, N, R + (size_t)2 * b * N);
-        double* r2 = (want_grad && prior) ? R2 : nullptr;
-        if (pl == ps) {
-            NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R, 2 * B, r2));
-        } else {
-            for (int b = 0; b < B; ++b) {
-                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, pl, R + (size_t)2 * b * N, 1, r2 ? r2 + (size_t)2 * b * N : nullptr));
-                NMGP_TRY(prior_solve(c, pscope.hb, pscope.sp, ps, R + (size_t)(2 * b + 1) * N, 1, r2 ? r2 + (size_t)(2 * b + 1) * N : nullptr));
-            }
-        }
-        col_sumsq(pscope.sp, R, N, N, 2 * B, dq);
-    }
-    pscope.done();
-    pscope.join();
-    std::vector<double> hr((size_t)BM * 4), hq((size_t)2 * B);
-    std::vector<int> hi(BM);
-    double hl[2];
-    HIP_TRY(c, hipMemcpyAsync(hr.data(), red, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(hi.data(), info, (size_t)BM * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(hq.data(), dq, hq.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&hl[0], pl->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&hl[1], ps->logdet, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    // chunk of chains: the device slab below the cap, the chain x block index within the grid's z limit
+    double cap_gb = 96.0;
+    if (const char* e = std::getenv("NMGP_SEP_BATCH_SLAB_GB")) cap_gb = std::max(1.0, std::atof(e));
+    const size_t per_chain = sep_batch_layout(1, N, M, T, want_grad).total * sizeof(double);
+    int Bc = (int)std::min<double>((double)B, std::floor(cap_gb * 1e9 / (double)per_chain));
+    Bc = std::min(Bc, 65535 / std::max(M, 1));
+    if (Bc < 1)
+        return nmgp_fail(c, NMGP_E_SHAPE, "one chain of the separable model at N = %d, D = %d needs %.1f GB of device workspace, above the "
+                         "NMGP_SEP_BATCH_SLAB_GB cap of %.0f GB", N, M, per_chain / 1e9, cap_gb);
     std::vector<char> bad(B, 0);
-    std::vector<double> lp_uL(B, 0.0), lp_s2(B);
-    std::vector<std::vector<double>> g_uL_prior(B, std::vector<double>(T, 0.0));
-    for (int b = 0; b < B; ++b) {
-        double ll = 0.0;
-        for (int p = 0; p < M; ++p) {
-            if (hi[(size_t)b * M + p] != 0) bad[b] = 1;
-            ll += -0.5 * hr[((size_t)b * M + p) * 4] - 0.5 * hr[((size_t)b * M + p) * 4 + 1];
-        }
-        if (!std::isfinite(ll)) bad[b] = 1;
-        const double* pb = pars + (size_t)b * P;
-        const double lp_l = -0.5 * (N * LOG2PI + hq[(size_t)2 * b]) - hl[0];
-        const double lp_s = -0.5 * (N * LOG2PI + hq[(size_t)2 * b + 1]) - hl[1];
-        for (int t = 0; t < T; ++t) lp_uL[b] += normal_logprob_f32(pb[2 * N + t], 0.0, cc, &g_uL_prior[b][t]);
-        lp_s2[b] = (-a - 1.0) * std::log(sig2[b]) - bb / sig2[b] + a * std::log(bb) - std::lgamma(a);
-        double res = ll;
-        if (prior) { res += lp_l; res += lp_s; res += lp_uL[b]; res += lp_s2[b]; res += tse[b]; }
-        double* o = out6 + (size_t)b * 6;
-        o[0] = -res; o[1] = ll; o[2] = lp_l; o[3] = lp_s; o[4] = lp_uL[b]; o[5] = lp_s2[b];
-        status[b] = 0;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = std::min(Bc, B - b0);
+        std::vector<char> badc(nb, 0);
+        NMGP_TRY(sep_batch_core(c, pars + (size_t)b0 * P, nb, hyper, prior, out6 + (size_t)b0 * 6, want_grad ? grad + (size_t)b0 * P : nullptr,
+                                status + b0, badc));
+        for (int k = 0; k < nb; ++k) bad[b0 + k] = badc[k];
     }
-    if (want_grad) {
-        double *Cneg = slab + o_Cneg, *part = slab + o_part, *C = slab + o_C, *W = slab + o_W, *Xi = slab + o_Xi, *d_g = slab + o_g;
-        double* trs = slab + o_tr;
-        const double one = 1.0, zero = 0.0;
-        {
-            NmgpStage sp(c, NMGP_STAGE_INVERSE);
-            tri_gemv_upper(s, S + xoff, ld, N, z, alpha, part, BM, bs, (long long)tri_part);
-            syrk_lower(s, S + xoff, ld, Cneg, N, N, N, N, BM, bs, (long long)NN, 1);              // -S_bp^-1
-        }
-        int Gs = 0;
-        {
-            NmgpStage sp(c, NMGP_STAGE_ADJOINT);
-            for (int b = 0; b < B; ++b) {
-                if (bad[b]) continue;
-                const double* sm = d_small + (size_t)b * small_per;
-                double* al = alpha + (size_t)b * M * N;
-                const double* Cn = Cneg + (size_t)b * M * NN;
-                Gs = sep_traces(s, Cn, dK + (size_t)b * NN, al, N, M, trs + (size_t)b * M * G * 3);
-                if (Gs != G) return nmgp_fail(c, NMGP_E_STATE, "sep_traces group count %d differs from the batch layout's %d", Gs, G);
-                weighted_sum_lower(s, Cn, sm, N, M, C);
-                fill_lower_to_full(s, C, N, N);
-                sep_adjoint(s, c->d_x, d_ell + (size_t)b * N, d_sig + (size_t)b * N, al, sm, M, C, N, part);
-                sep_grad_sum(s, part, NJ, N, d_g + (size_t)b * 2 * N);
-                HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)N * M * sizeof(double), s));
-                BLAS_TRY(c, rocblas_dsymm(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, dK + (size_t)b * NN, N, al, N, &zero, W, N));
-                BLAS_TRY(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, al, N, W, N, &zero,
-                                          Xi + (size_t)b * M * M, M));
-            }
-        }
-        std::vector<double> hx((size_t)B * M * M, 0.0), hg((size_t)B * 2 * N, 0.0), hR2((size_t)N * 2 * B, 0.0), htr((size_t)BM * G * 3, 0.0);
-        HIP_TRY(c, hipMemcpyAsync(hx.data(), Xi, hx.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(hg.data(), d_g, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(htr.data(), trs, htr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (prior) HIP_TRY(c, hipMemcpyAsync(hR2.data(), R2, hR2.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        for (int b = 0; b < B; ++b) {
-            if (bad[b]) continue;
-            std::vector<double> tr(M, 0.0), tk(M, 0.0), aa(M, 0.0);
-            // sep_traces wrote M * Gs * 3 doubles contiguously at trs + b * M * G * 3
-            const double* tb = htr.data() + (size_t)b * M * G * 3;
-            for (int p = 0; p < M; ++p)
-                for (int g = 0; g < Gs; ++g) {
-                    tr[p] += tb[((size_t)p * Gs + g) * 3];
-                    tk[p] += tb[((size_t)p * Gs + g) * 3 + 1];
-                    aa[p] += tb[((size_t)p * Gs + g) * 3 + 2];
-                }
-            std::vector<double> Xs((size_t)M * M), dB((size_t)M * M, 0.0), g_uL;
-            const double* hxb = hx.data() + (size_t)b * M * M;
-            for (int p = 0; p < M; ++p)
-                for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (hxb[(size_t)q * M + p] - (p == q ? tk[p] : 0.0));
-            for (int i = 0; i < M; ++i)
-                for (int j = 0; j < M; ++j) {
-                    double acc = 0.0;
-                    for (int p = 0; p < M; ++p)
-                        for (int q = 0; q < M; ++q) acc += w[b].h_VB[(size_t)i * M + p] * Xs[(size_t)p * M + q] * w[b].h_VB[(size_t)j * M + q];
-                    dB[(size_t)i * M + j] = acc;
-                }
-            double ds = 0.0;
-            for (int p = 0; p < M; ++p) ds += 0.5 * (aa[p] - tr[p]);
-            dB_to_guL(dB, w[b].h_L, M, g_uL);
-            double* gb = grad + (size_t)b * P;
-            for (int i = 0; i < 2 * N; ++i) {
-                // (R2 holds the chain's two solved columns [tilde_l | tilde_sigma] back to back: the layout of the 2N leading parameters)
-                const double r = prior ? hR2[(size_t)2 * b * N + i] : 0.0;
-                gb[i] = -(hg[(size_t)b * 2 * N + i] - r);
-            }
-            for (int t = 0; t < T; ++t) gb[2 * N + t] = -(g_uL[t] + (prior ? g_uL_prior[b][t] : 0.0));
-            double ge = sig2[b] * ds;
-            if (prior) ge += (-a - 1.0) + bb / sig2[b] + 1.0;
-            gb[P - 1] = -ge;
-        }
-    }
-    NMGP_TRY(nmgp_take_launch_error(c));
     // chains that failed numerically: the single-chain entry, with the reference's jitter retries
     for (int b = 0; b < B; ++b)
         if (bad[b]) NMGP_TRY(one_by_one(b));

@@ -380,6 +380,16 @@ void sep_blocks(hipStream_t s, const double* K, const double* wB, const double* 
 #define NMGP_SEP_TR_G 128      // partial sums per block that sep_traces leaves for the host: out[(p * NMGP_SEP_TR_G + g) * 3 + {tr, tk, aa}]
 int sep_traces(hipStream_t s, const double* Cneg, const double* K, const double* alpha, int N, int M, double* out);
 void weighted_sum_lower(hipStream_t s, const double* Cneg, const double* wB, int N, int M, double* C);
+// ---- nmgp_kernels_sep.hip: the separable objective's pieces with the chain as a grid dimension (nmgp_sep_batch_eval) ----
+void sep_prep_b(hipStream_t s, const double* pars, long long P, const double* Y, const double* small, int small_per, int N, int M,
+                double* ell, double* sig, double* yt, int B);
+void sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per, int N, int M,
+                  double* S, int ldo, long long bstride, double* Kout, int B);
+void sep_reduce_b(hipStream_t s, const double* Cneg, const double* K, const double* alpha, const double* small, int small_per, int N,
+                  int M, int G, double* C, double* out, int B);
+void sep_adjoint_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* U, const double* small,
+                   int small_per, int M, const double* C, int N, double* part, double* g, int B);
+void two_col_rhs_b(hipStream_t s, const double* pars, long long P, double mu_a, double mu_b, int N, double* R, int B);
 // ---- nmgp_chol.hip ----
 void syrk_lower(hipStream_t s, const double* A, int lda, double* C, int ldc, int mrows, int ncols, int K, int batch,
                 long long bstride, long long cstride = -1, int ktri = 0, int tri_row0 = 0x7fffffff, int tri_k0 = 0);

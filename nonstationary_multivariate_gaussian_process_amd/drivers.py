@@ -579,10 +579,15 @@ class BatchedHMC(LockStepHMC):
     """
 
     def __init__(self, x, Y, hyper_pars, init_positions, step_size=1e-4, num_steps_in_leap=20, seed=None, ctx=None,
-                 device_resident=True, M=None, Minv=None, chains_per_subject=1, device_momenta=None):
+                 device_resident=True, M=None, Minv=None, chains_per_subject=1, device_momenta=None, step_jitter=0.0):
         from . import _lib
         super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
         self.device_resident = bool(device_resident)
+        # step_jitter j > 0: iteration i uses eps (1 + j u_i), u_i ~ U(-1, 1) from a generator of its own (the chains' streams are
+        # untouched), the same step for all chains of the iteration -- the usual guard against a trajectory length that resonates
+        # with the posterior's periods (under a PriorMetric they are all ~2 pi).  Device-resident loop only.
+        self.step_jitter = float(step_jitter)
+        self.jitter_rng = np.random.default_rng(None if seed is None else 7919 * (seed + 1))
         # device_momenta: the host only draws the standard normals z; p0 = chol(M) z and the end point's kinetic energy
         # 1/2 p1^T M^-1 p1 are formed on the device (nmgp_svc_batch_traj_z).  Default: on whenever a mass matrix is set -- the
         # host's share of a dense-mass sample was two [B, P] x [P, P] NumPy products -- off for the identity (where it would only
@@ -642,18 +647,19 @@ class BatchedHMC(LockStepHMC):
         t_loop = time.perf_counter()
         t_traj = 0.0
         for it in range(sample_size):
+            eps = self.eps if self.step_jitter <= 0 else self.eps * (1.0 + self.step_jitter * self.jitter_rng.uniform(-1.0, 1.0))
             if self.device_momenta:
                 # the same random stream: chain b draws its P standard normals, then (below) the accept uniform
                 z = np.stack([r.standard_normal(P) for r in self.rngs])
                 H0 = U + 0.5 * (z * z).sum(1)            # p0 = chol(M) z  =>  1/2 p0^T M^-1 p0 = 1/2 |z|^2
                 t0 = time.perf_counter()
-                q1, K1, U1, failed = self.ctx.svc_batch_traj_z(self.hyper, True, self.eps, self.L, z)
+                q1, K1, U1, failed = self.ctx.svc_batch_traj_z(self.hyper, True, eps, self.L, z)
                 t_traj += time.perf_counter() - t0
             else:
                 p0 = self.draw_momenta()
                 H0 = U + self.kinetic(p0)
                 t0 = time.perf_counter()
-                q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, self.eps, self.L, p0)
+                q1, p1, U1, failed = self.ctx.svc_batch_traj(self.hyper, True, eps, self.L, p0)
                 t_traj += time.perf_counter() - t0
                 K1 = self.kinetic(p1)
             U1 = np.where(failed, np.inf, U1)

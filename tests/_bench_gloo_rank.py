@@ -15,4 +15,8 @@ if __name__ == "__main__":
     if os.environ.get("NMGP_TEST_FAIL_RANK") == os.environ.get("RANK"):
         print("rank %s: failing on purpose" % os.environ.get("RANK"), flush=True)
         sys.exit(3)
+    if os.environ.get("NMGP_TEST_HANG_RANK") == os.environ.get("RANK"):
+        import time
+        print("rank %s: hanging on purpose" % os.environ.get("RANK"), flush=True)
+        time.sleep(3600)
     bench.main(sys.argv[1:], backend=GlooOracleBackend())

@@ -86,7 +86,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "parity_%s.json" % os.environ.get("NMGP_ROUND", "r04"))
+    path = os.path.join(out_dir, "parity_%s.json" % os.environ.get("NMGP_ROUND", "r05"))
     worst = {}
     for row in _PARITY:
         for k, v in row.items():

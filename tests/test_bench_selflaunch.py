@@ -44,6 +44,21 @@ def test_self_launch_propagates_a_failing_rank(monkeypatch):
     assert rc != 0 and buf.getvalue() == ""
 
 
+def test_self_launch_kills_ranks_that_hang(monkeypatch):
+    """A rank that never finishes (first contact with RCCL is the case this guards) keeps the child's stdout open: the timeout must
+    still fire, the launcher child must be killed and a non-zero code returned."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("NMGP_TEST_HANG_RANK", "1")
+    buf = io.StringIO()
+    t0 = time.time()
+    rc = bench.self_launch(ARGS, 2, script=RANK_SCRIPT, out=buf, timeout=25)
+    assert rc == 124 and buf.getvalue() == "" and time.time() - t0 < 120
+
+
 def test_bench_main_becomes_the_launcher_before_touching_the_gpu(monkeypatch):
     """bench.py --gpus 2 as a program, without WORLD_SIZE: main() must call self_launch (and nothing else) -- in this container the
     ranks then fail loudly because there is no GPU, and the parent exits non-zero without having imported torch."""

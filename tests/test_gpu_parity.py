@@ -143,6 +143,11 @@ def test_python_mirror_autograd_matches_reference(ctx):
     (gp,) = torch.autograd.grad(v, p)
     assert relerr(float(v), g["out"][0]) < VAL_TOL and vec_relerr(gp.numpy(), g["grad"]) < GRAD_TOL
     assert isinstance(float(-v), float)                       # target_value_hist[i] = -NegLog (Nonseparable_model.py:183)
+    # a read-only evaluation of a tensor that requires grad (Stationary_model.py:112,168 style): under torch.no_grad() the mirror asks
+    # the library for the value alone (no gradient is computed or kept) and returns the same numbers
+    with torch.no_grad():
+        ro = Utility.logpos.nlogpos_obj_SVC(p, Y, x, **h, verbose=True)
+    assert not ro[0].requires_grad and relerr([float(o) for o in ro], g["out"]) < VAL_TOL
     K = Utility.kernels.Nonstationary_RBF_cov(x.view(-1, 1), ell1=torch.exp(tilde_l.detach()))
     assert np.allclose(K.numpy(), g["Kx"], rtol=1e-13, atol=0)
 
@@ -891,6 +896,34 @@ def test_sixteen_chain_gradient_batch_on_the_wide_panel_schedule(ctx):
         so, sg = ctx.logpos_svc(pars[k], g["hyper"], prior=True, want_grad=True)
         record_parity("gradbatch16_chain%d_vs_single" % k, loglik=(relerr(out[k][1], so[1]), 1e-11), grad=(vec_relerr(grads[k], sg), 1e-8))
         assert relerr(out[k][1], so[1]) < 1e-11 and vec_relerr(grads[k], sg) < 1e-8, (k, vec_relerr(grads[k], sg))
+    ctx.svc_batch_alloc(1)
+
+
+def test_headline_gradient_batch_of_128_chains_at_N2048(ctx):
+    """The shape bench.py's `grad` object and the 128-chain HMC measurement time (Nonseparable_model.py:169-171: value, then
+    backward): 128 chains x n = 6144 value+gradient in one launch sequence -- 128 L^-T row blocks riding through the 2048-wide
+    panels, the inverse SYRK of 128 matrices, the adjoint pass with blockIdx.z = 128.  Chain 0 carries the golden parameters
+    (reference value + autograd gradient committed), three other chains are compared with single-chain evaluations, every status
+    is 0 and every number finite."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    g = golden("svc_sim_N2048_M3_base")
+    ctx.set_data(g["x"], g["Y"])
+    B = 128
+    ctx.svc_batch_alloc(B)
+    pars = np.stack([sim.perturb(g["pars"], 0.002 * k, 0.37 * k) for k in range(B)])
+    pars[0] = g["pars"]
+    ctx.svc_batch_set_pars(pars)
+    ctx.svc_batch_eval(g["hyper"], True, True)
+    out, status = ctx.svc_batch_fetch()
+    grads = ctx.svc_batch_fetch_grad()
+    assert np.all(status == 0) and np.all(np.isfinite(out)) and np.all(np.isfinite(grads))
+    record_parity("gradbatch128_chain0_vs_golden", neglog=(relerr(out[0][0], g["out"][0]), VAL_TOL),
+                  grad=(vec_relerr(grads[0], g["grad"]), GRAD_TOL))
+    assert relerr(out[0], g["out"]) < VAL_TOL and vec_relerr(grads[0], g["grad"]) < GRAD_TOL
+    for k in (1, 63, 127):
+        so, sg = ctx.logpos_svc(pars[k], g["hyper"], prior=True, want_grad=True)
+        record_parity("gradbatch128_chain%d_vs_single" % k, loglik=(relerr(out[k][1], so[1]), 1e-11), grad=(vec_relerr(grads[k], sg), 1e-8))
+        assert relerr(out[k][1], so[1]) < 1e-11 and relerr(out[k], so) < 1e-9 and vec_relerr(grads[k], sg) < 1e-8, (k, vec_relerr(grads[k], sg))
     ctx.svc_batch_alloc(1)
 
 

@@ -1,5 +1,5 @@
 set -e
-R=${1:-r04}
+R=${1:-r05}
 mkdir -p gpurun_out/${R}_final
 export NMGP_ROUND=$R
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/${R}_final/pytest.txt 2>&1 || { tail -30 gpurun_out/${R}_final/pytest.txt; exit 1; }

@@ -111,7 +111,11 @@ def main():
     ap.add_argument("--mass", choices=["prior", "diag", "identity"], default="prior")
     ap.add_argument("--rank", type=int, default=96)
     ap.add_argument("--probe-h", type=float, default=1e-3)
-    ap.add_argument("--polish", type=int, default=300, help="L-BFGS iterations on the committed Adam MAP estimate before the metric is built (0 = none)")
+    ap.add_argument("--warm", type=int, default=40, help="mass prior: thermalising iterations from the MAP point at a small step before the step search")
+    ap.add_argument("--jitter", type=float, default=0.2, help="mass prior: the step of iteration i is eps (1 + jitter u_i), u_i ~ U(-1, 1)")
+    ap.add_argument("--save-state", default="", help="write the polished MAP point and the chains' final (typical-set) positions to this .npz "
+                                                     "(bench.py's `hmc` object starts from it: tests/golden/hmc_state_N2048_M3_seed2222.npz)")
+    ap.add_argument("--polish", type=int, default=2000, help="L-BFGS iterations on the committed Adam MAP estimate before the metric is built (0 = none)")
     ap.add_argument("--step", default="auto")
     ap.add_argument("--leap", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hmc_1000.json"))
@@ -156,6 +160,21 @@ def main():
         rec["metric"] = dict(met.info, seconds=dtm, rank=met.rank)
         mass_kw = {"M": met}
         q_start = q0
+        if a.warm > 0:
+            # All chains start AT the mode: potential minimal, so the first trajectories turn P/2 ~ 7000 units of kinetic energy into
+            # potential energy and the leapfrog error of that transfer (~ eps^2 E / 8) would reject every step size worth having.
+            # A few iterations at a small step put the chains into the typical set; the step search starts from there.
+            t0 = time.time()
+            hw = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q0, step_size=0.03, num_steps_in_leap=a.leap, seed=300, **mass_kw)
+            sw, iw = hw.run(a.warm)
+            q_start = sw[-1]
+            rec["warm_up"] = {"iterations": a.warm, "step_size": 0.03, "seconds": time.time() - t0,
+                              "accept_rate_mean": float(iw["accept_rate"].mean()),
+                              "median_abs_dH_first_5": float(np.nanmedian(np.abs(iw["energy_error"][:5]))),
+                              "median_abs_dH_last_10": float(np.nanmedian(np.abs(iw["energy_error"][-10:])))}
+            note("warm-up: %d iterations at eps 0.03 in %.1f s, accept %.2f, median |dH| first 5 %.3g, last 10 %.3g" % (
+                a.warm, time.time() - t0, iw["accept_rate"].mean(), rec["warm_up"]["median_abs_dH_first_5"],
+                rec["warm_up"]["median_abs_dH_last_10"]))
         note("metric: rank %d of %d probes in %.1f s (%d gradient evaluations), lam max %.3g, last kept %.3g, first dropped %s" % (
             met.rank, met.info["probes"], dtm, met.info["grad_evals"], met.info["lam_max"], met.info["lam_min_kept"],
             met.info["first_dropped"]))
@@ -182,7 +201,7 @@ def main():
         # parameter moves as far per step as under the identity mass at eps_id
         if a.mass == "prior":
             # whitened coordinates: the posterior is ~N(0, I) in P dimensions, so eps ~ P^-1/4; 20 steps of 0.08 = a quarter period
-            cands = [0.04, 0.06, 0.08, 0.11, 0.15]
+            cands = [0.05, 0.065, 0.08, 0.1, 0.12]
         else:
             base = eps_id if a.mass == "identity" else eps_id / float(np.sqrt(np.median(mass_kw["Minv"])))
             cands = [base * f for f in ((0.5, 1.0, 2.0) if a.mass == "identity" else (0.5, 1.0, 2.0, 4.0, 8.0, 16.0))]
@@ -190,7 +209,7 @@ def main():
         best = None
         for eps in cands:
             hs = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=200, **mass_kw)
-            _, isr = hs.run(4)
+            _, isr = hs.run(4 if a.mass != "prior" else 6)
             acc = float(isr["accept_rate"].mean())
             med = float(np.nanmedian(np.abs(isr["energy_error"])))
             tried.append({"step_size": eps, "accept_rate_mean": acc, "median_abs_dH": med})
@@ -209,7 +228,10 @@ def main():
                    "prior": "prior-factor metric M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T (nmgp_svc_batch_traj_set_mass_prior): cached "
                             "GP-prior Cholesky factors + rank-%d likelihood correction, whitened momenta on the device" % (
                                 mass_kw["M"].rank if a.mass == "prior" else 0)}[a.mass]
-    hm = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=1, **mass_kw)
+    jit = a.jitter if a.mass == "prior" else 0.0
+    rec["step_jitter"] = jit
+    hm = drivers.BatchedHMC(d["x"], d["Y"], sim.HYPER_SVC, q_start, step_size=eps, num_steps_in_leap=a.leap, seed=1, step_jitter=jit,
+                            **mass_kw)
     # run in segments so that progress is visible
     seg = 50
     chunks, accs, ees = [], [], []
@@ -272,6 +294,11 @@ def main():
     rec["rms_displacement_from_start_per_parameter"] = float(np.sqrt(np.mean((S[-1] - q_start) ** 2)))
     rec["log_sigma2"] = {"truth": float(d["pars_true"][-1]), "map": float(qmap[-1]), "posterior_mean": float(Sb[:, :, -1].mean()),
                          "posterior_sd": float(Sb[:, :, -1].std())}
+    if a.save_state:
+        np.savez_compressed(a.save_state, pars_polished=qmap, pars_typical=S[-1], step_size=eps, iterations=a.iters, chains=B,
+                            accept_rate_mean=float(acc.mean()), seed=seed, N=N, M=M,
+                            made_by="tools/hmc_1000.py --mass %s --iters %d --chains %d (GPU run; see profiles/r05_hmc_1000.json)" % (a.mass, a.iters, B))
+        note("state written to %s" % a.save_state)
     with open(a.out, "w") as f:
         json.dump(rec, f, indent=1)
     note("wrote %s: %.2f samples/s, accept %.3f" % (a.out, rec["main"]["samples_per_s"], acc.mean()))
