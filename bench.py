@@ -365,6 +365,16 @@ def map_point(N, M, seed):
     return g
 
 
+def hmc_state(N, M, seed):
+    """The committed sampler state of the subject (N, M, data seed): polished MAP point + typical-set positions, or None."""
+    path = os.path.join(ROOT, "tests", "golden", "hmc_state_N%d_M%d_seed%d.npz" % (N, M, seed))
+    if not os.path.exists(path):
+        return None
+    g = dict(np.load(path))
+    g["path"] = path
+    return g
+
+
 def chain_parameters(sim, d, B):
     """Chain b starts from its own smooth perturbation of the generating parameters."""
     return np.stack([sim.perturb(d["pars_true"], 0.05, 0.7 + 0.37 * b) for b in range(B)])
@@ -391,12 +401,27 @@ def hmc_measure(a, kind, rank, world, be, ev, prof, d, hyper, allp, B):
     mass_kw, mass_note, step = {}, "identity mass matrix", a.hmc_step
     metric_rec = None
     if kind == "prior":
+        # the metric is built at the MODE (the Adam estimate polished by L-BFGS) and the chains start from typical-set positions of
+        # a previous run under this metric -- both committed for rank 0's subject (tests/golden/hmc_state_*.npz, written by
+        # tools/hmc_1000.py --save-state); chains started AT the mode would spend their first trajectories converting P/2 units
+        # of kinetic energy, whose leapfrog error rejects any step worth having (profiles/r05_hmc_1000.json: warm_up)
+        st = hmc_state(N, M, 2222 + rank)
+        q_ref = q0[0]
+        step = a.hmc_prior_step
+        if st is not None:
+            q_ref = st["pars_polished"]
+            typ = st["pars_typical"]
+            q0 = np.stack([typ[b % typ.shape[0]] for b in range(B)])
+            start = ("typical-set positions of the %d chains of tools/hmc_1000.py's run under this metric (tests/golden/%s; chain b starts "
+                     "from position b mod %d with its own momenta), metric built at the polished MAP point" % (
+                         typ.shape[0], os.path.basename(st["path"]), typ.shape[0]))
+        else:
+            step = min(step, 0.03)          # from the (unpolished) MAP point itself: a thermalising step
         t0 = time.perf_counter()
-        met = drivers.prior_lowrank_metric(d["x"], d["Y"], hyper, q0[0], rank=a.hmc_rank, oversample=32, power_iters=1, seed=7, ctx=prof,
+        met = drivers.prior_lowrank_metric(d["x"], d["Y"], hyper, q_ref, rank=a.hmc_rank, oversample=32, power_iters=1, seed=7, ctx=prof,
                                            batch=B)
         metric_rec = dict({k: v for k, v in met.info.items() if k != "eigenvalues"}, seconds=time.perf_counter() - t0, rank=met.rank)
         mass_kw = {"M": met}
-        step = a.hmc_prior_step
         mass_note = ("prior-factor metric M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T (cached GP-prior Cholesky factors + rank-%d "
                      "likelihood correction; whitened momenta, no [P, P] matrix)" % met.rank)
     elif kind != "identity":

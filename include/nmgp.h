@@ -91,7 +91,9 @@ int nmgp_svc_fetch(nmgp_ctx* ctx, double out5[5], double* grad);
  * launch sequence -- every kernel takes the chain as a grid dimension, so the latency-bound panel steps of the
  * factorisation are paid once per batch.  This is the throughput path of MCMC with
  * many chains (the reference runs its chains as separate processes, Nonseparable_model_mpisim.py:305-306).
- * nmgp_svc_batch_alloc sizes B covariance buffers (B * 8 * MN * (MN+1) bytes); nmgp_svc_batch_eval only enqueues;
+ * nmgp_svc_batch_alloc sizes B covariance buffers (B * 8 * MN * (MN+1) bytes; called again with the SAME B it keeps every buffer --
+ * the gradient workspace of 128 chains at the headline size is 116 GB, seconds of allocation -- and only resets the batch's state:
+ * chains of the resident subject, identity metric, no trajectory / optimiser, zero parameters); nmgp_svc_batch_eval only enqueues;
  * nmgp_svc_batch_fetch synchronises and returns out[B,5] and per-chain status[B] (0 ok; k>0 leading minor k not
  * positive definite; NMGP_NUM_NAN) -- a failing chain yields NaNs in its row, not a failed call. */
 int nmgp_svc_batch_alloc(nmgp_ctx* ctx, int B);

@@ -700,6 +700,29 @@ extern "C" int nmgp_svc_batch_alloc(nmgp_ctx* c, int B) {
     if (B <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "batch size must be positive");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (B == c->batch && c->b_pars) {
+        // The same batch size again (every sampler / optimiser object starts with this call): the B-sized buffers -- 116 GB of
+        // factorisation and inverse workspace for 128 gradient chains at the headline size, seconds of hipMalloc -- are kept;
+        // only the STATE goes back to that of a fresh batch: chains of the resident subject, identity metric, no trajectory, no
+        // optimiser, zero parameters.
+        mass_reset(c);
+        c->b_multi = false;
+        c->b_cps = 1;
+        if (c->b_x) hipFree(c->b_x);
+        if (c->b_y) hipFree(c->b_y);
+        c->b_x = c->b_y = nullptr;
+        for (auto& pf : c->b_priors) {
+            if (pf.L) hipFree(pf.L);
+            if (pf.logdet) hipFree(pf.logdet);
+        }
+        c->b_priors.clear();
+        c->b_adam_t = -1;
+        c->b_traj_ready = false;
+        c->b_last_grad = false;
+        if (c->last_kind == 2) c->last_kind = 0;           // no batched evaluation is pending any more
+        HIP_TRY(c, hipMemsetAsync(c->b_pars, 0, (size_t)B * c->P_svc * sizeof(double), c->stream));
+        return 0;
+    }
     free_batch(c);
     const size_t N = c->N, T = c->T, n = c->n, P = (size_t)c->P_svc;
     const size_t ld = nmgp_ld(n + 1);

@@ -58,14 +58,15 @@ void sep_prep_b(hipStream_t s, const double* pars, long long P, const double* Y,
 
 // Lower triangles of the M blocks of chain b = blockIdx.z, and of K_x,b itself when Kout != nullptr (kernels.py:46-73 with the
 // jitter on the diagonal, then logpos.py:258-262's B kron K + sigma2 I in B's eigenbasis).  64 x 64 location tile per workgroup,
-// j-side inputs in LDS, lanes along i: every store instruction writes 512 contiguous bytes of a column.
+// j-side inputs in LDS, lanes along i: every store instruction writes 512 contiguous bytes of a column.  M is a template parameter
+// so that the block weights live in registers and the M stores of an element are straight-line code.
+template <int M>
 __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__ x, const double* __restrict__ ell,
                                                        const double* __restrict__ sig, const double* __restrict__ small,
-                                                       int small_per, int N, int M, double* __restrict__ S, int ldo,
-                                                       long long bstride, double* __restrict__ Kout) {
+                                                       int small_per, int N, double* __restrict__ S, int ldo, long long bstride,
+                                                       double* __restrict__ Kout) {
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], ss[TJ];
-    __shared__ double swB[NMGP_MAX_OUTPUTS + 1];
     const int I = blockIdx.x, J = blockIdx.y, b = blockIdx.z;
     if (I < J) return;
     const double* eb = ell + (size_t)b * N;
@@ -79,16 +80,18 @@ __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__
         sl[tid] = (j < N) ? eb[j] : 1.0;
         ss[tid] = (j < N) ? sb[j] : 1.0;
     }
-    if (tid >= 64 && tid < 64 + M) swB[tid - 64] = sm[tid - 64];
-    if (tid == 128) swB[NMGP_MAX_OUTPUTS] = sm[M + (size_t)M * M];       // sigma2
     __syncthreads();
     const int i = I * 64 + lane;
     if (i >= N) return;
+    double wB[M];
+#pragma unroll
+    for (int p = 0; p < M; ++p) wB[p] = sm[p];
+    const double sigma2 = sm[M + M * M];
     const double xi = x[i], li = eb[i], si = sb[i];
     const double xi2 = xi * xi, li2 = li * li;
-    const double sigma2 = swB[NMGP_MAX_OUTPUTS];
-    double* Sb = S + (size_t)b * M * bstride;
-    double* Kb = Kout ? Kout + (size_t)b * N * N : nullptr;
+    double* Sb = S + (size_t)b * M * bstride + i;
+    double* Kb = Kout ? Kout + (size_t)b * N * N + i : nullptr;
+#pragma unroll 2
     for (int jj = 0; jj < TJ / 4; ++jj) {
         const int k = w * (TJ / 4) + jj;
         const int j = j0 + k;
@@ -99,19 +102,36 @@ __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__
         const double A = li2 + lj * lj;
         double v = (si * ss[k]) * sqrt(2.0 * (li * lj) / A) * exp(-dist / A);   // kernels.py:69-72
         if (i == j) v = NMGP_JITTER + v;
-        if (Kb) Kb[(size_t)j * N + i] = v;
+        if (Kb) Kb[(size_t)j * N] = v;
+        const size_t col = (size_t)j * ldo;
+#pragma unroll
         for (int p = 0; p < M; ++p) {
-            double o = swB[p] * v;
+            double o = wB[p] * v;
             if (i == j) o += sigma2;
-            Sb[(size_t)p * bstride + (size_t)j * ldo + i] = o;
+            Sb[(size_t)p * bstride + col] = o;
         }
     }
 }
 
+template <int M>
+static void launch_sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per,
+                                int N, double* S, int ldo, long long bstride, double* Kout, int B) {
+    NMGP_LAUNCH((k_sep_blocks_b<M>), dim3(cdiv_s(N, 64), cdiv_s(N, 64), B), dim3(256), 0, s, x, ell, sig, small, small_per, N, S, ldo,
+                bstride, Kout);
+}
+
 void sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per, int N, int M,
                   double* S, int ldo, long long bstride, double* Kout, int B) {
-    NMGP_LAUNCH(k_sep_blocks_b, dim3(cdiv_s(N, 64), cdiv_s(N, 64), B), dim3(256), 0, s, x, ell, sig, small, small_per, N, M, S, ldo,
-                bstride, Kout);
+    switch (M) {
+        case 1: launch_sep_blocks_b<1>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 2: launch_sep_blocks_b<2>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 3: launch_sep_blocks_b<3>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 4: launch_sep_blocks_b<4>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 5: launch_sep_blocks_b<5>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 6: launch_sep_blocks_b<6>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        case 7: launch_sep_blocks_b<7>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;
+        default: launch_sep_blocks_b<8>(s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, B); break;      // (M <= NMGP_MAX_OUTPUTS)
+    }
 }
 
 // ONE pass over the M blocks Cneg_bp = -S_bp^-1 (lower, ld = N) of chain b = blockIdx.y; workgroup g = blockIdx.x takes the columns

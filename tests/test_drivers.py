@@ -404,6 +404,48 @@ def test_trajectory_state_is_invalidated_by_a_new_metric_or_new_subjects():
 
 
 @pytest.mark.gpu
+def test_allocating_the_same_batch_size_again_keeps_the_buffers_and_resets_the_state():
+    """Every sampler / optimiser object starts with nmgp_svc_batch_alloc(B); with an unchanged B the call must not free and
+    re-allocate the batch (116 GB of gradient workspace at the headline size: 5 s of every sampler construction in round 4), but it
+    must hand back a FRESH batch: zero parameters, identity metric, no trajectory begun, chains of the resident subject."""
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    g = golden("svc_rngfree_N32_M2")
+    hv = g["hyper"]
+    B = 3
+    c = _lib.Context(0)
+    try:
+        c.set_data(g["x"], g["Y"])
+        c.svc_batch_alloc(B)
+        q = np.stack([sim.perturb(g["pars"], 0.01, 0.3 * b) for b in range(B)])
+        P = q.shape[1]
+
+        def evaluate():
+            c.svc_batch_set_pars(q)
+            c.svc_batch_eval(hv, True, want_grad=True)
+            out, st = c.svc_batch_fetch()
+            return out, c.svc_batch_fetch_grad()
+        out1, g1 = evaluate()
+        dev1 = c.lib.nmgp_svc_batch_pars_dev(c.h)
+        c.svc_batch_traj_set_mass(np.full(P, 2.0))
+        c.svc_batch_set_subjects(np.stack([g["x"]] * B), np.stack([g["Y"]] * B))
+        c.svc_batch_alloc(B)                                  # the same size again
+        assert c.lib.nmgp_svc_batch_pars_dev(c.h) == dev1     # same buffers ...
+        assert np.all(c.svc_batch_get_pars() == 0.0)          # ... fresh state
+        with pytest.raises(_lib.NmgpError, match="value\\+gradient evaluation"):
+            c.svc_batch_traj_begin()
+        out2, g2 = evaluate()                                 # chains of the resident subject again, bit for bit
+        assert np.array_equal(out1, out2) and np.array_equal(g1, g2)
+        c.svc_batch_traj_begin()
+        z = np.random.default_rng(0).standard_normal((B, P))
+        q1, kin, U1, failed = c.svc_batch_traj_z(hv, True, 1e-5, 2, z)      # identity metric: no chol(M) needed
+        assert not failed.any() and np.allclose(kin, 0.5 * (z * z).sum(1), rtol=1e-3)
+        c.svc_batch_alloc(B + 1)                              # another size: a new batch
+        assert np.all(c.svc_batch_get_pars() == 0.0) and c.svc_batch_get_pars().shape == (B + 1, P)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_batched_separable_hmc_chains_follow_the_single_chain_sampler():
     """BatchedHMCSeparable: B chains of the separable model in lock-step on nmgp_sep_batch_eval; every chain reproduces
     HMCSampler(potential_func=logpos.nlogpos_obj, ...) -- the sampler call of Separable_model.py:209 -- from the same state with the

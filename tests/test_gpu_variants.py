@@ -223,7 +223,8 @@ def test_bench_launches_two_ranks_by_itself_and_rehearses_the_multi_process_path
     gloo process group (RCCL refuses two ranks on one device).  What a one-GPU box can execute of the N > 1 path, as one command."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--chains", "3", "--N", "96",
-                          "--steps", "2", "--warmup", "1", "--grad-steps", "1", "--hmc-samples", "1", "--no-cpu-baseline"],
+                          "--steps", "2", "--warmup", "1", "--grad-steps", "1", "--hmc-samples", "1", "--hmc-all-ranks", "--hmc-mass", "identity",
+                          "--cpu-evals", "1", "--cpu-grad-evals", "0"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -236,5 +237,5 @@ def test_bench_launches_two_ranks_by_itself_and_rehearses_the_multi_process_path
     assert len({r["pid"] for r in dr["ranks"]}) == 2 and all(r["device_ordinal"] == 0 for r in dr["ranks"])
     assert len({r["library_build_id"] for r in dr["ranks"]}) == 1 and dr["distinct_gpus"] == 1
     assert rec["config"]["chains_total"] == 6 and rec["config"]["chains_ok"] == 6 and rec["grad"]["chains_ok"] == 3
-    assert len(rec["hmc"]["by_rank"]) == 2 and rec["hmc"]["by_rank"][1]["rank"] == 1
-    assert "cpu_baseline" not in rec
+    assert len(rec["hmc"]["by_rank"]) == 2 and rec["hmc"]["by_rank"][1]["rank"] == 1      # (--hmc-all-ranks: off by default when N > 1)
+    assert rec["cpu_baseline"]["value"] > 0 and rec["hmc_samples_per_s"] == rec["hmc"]["samples_per_s"]      # a self-contained N = 2 line

@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--jitter", type=float, default=0.2, help="mass prior: the step of iteration i is eps (1 + jitter u_i), u_i ~ U(-1, 1)")
     ap.add_argument("--save-state", default="", help="write the polished MAP point and the chains' final (typical-set) positions to this .npz "
                                                      "(bench.py's `hmc` object starts from it: tests/golden/hmc_state_N2048_M3_seed2222.npz)")
-    ap.add_argument("--polish", type=int, default=2000, help="L-BFGS iterations on the committed Adam MAP estimate before the metric is built (0 = none)")
+    ap.add_argument("--polish", type=int, default=300, help="L-BFGS iterations on the committed Adam MAP estimate before the metric is built (0 = none)")
     ap.add_argument("--step", default="auto")
     ap.add_argument("--leap", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "hmc_1000.json"))
@@ -145,10 +145,10 @@ def main():
     if a.mass == "prior":
         if a.polish > 0:
             t0 = time.time()
-            qp, nl, gn, nev = drivers.polish_map(d["x"], d["Y"], sim.HYPER_SVC, qmap, maxiter=a.polish)
+            qp, nl, gn, nev = drivers.polish_map(d["x"], d["Y"], sim.HYPER_SVC, qmap, maxiter=a.polish, verbose=note)
             rec["map_polish"] = {"lbfgs_iterations_max": a.polish, "evaluations": nev, "seconds": time.time() - t0,
                                  "log_posterior_before": float(g["target_value_hist"][-1]), "log_posterior_after": -nl,
-                                 "gradient_norm_after": gn, "rms_change_per_parameter": float(np.sqrt(np.mean((qp - qmap) ** 2)))}
+                                 "whitened_gradient_norm_after": gn, "rms_change_per_parameter": float(np.sqrt(np.mean((qp - qmap) ** 2)))}
             note("polish: %d evaluations in %.1f s, log posterior %.4f -> %.4f, |grad| %.3g" % (
                 nev, time.time() - t0, float(g["target_value_hist"][-1]), -nl, gn))
             qmap = qp
