@@ -822,7 +822,10 @@ extern "C" int nmgp_sep_batch_eval(nmgp_ctx* c, const double* pars, int B, const
         }
         return 0;
     };
-    if (c->sep_algo != 1 || B == 1) {
+    // (the batched block kernel addresses a block with 32-bit byte offsets: (2N + 2) N 8 < 2^31, i.e. N <= 11,584 -- beyond that, and
+    // for the eigen formulation, the chains are evaluated one by one)
+    const bool blocks_fit = (long long)(2 * (long long)N + 18) * N * 8 < 0x7fffffffLL;
+    if (c->sep_algo != 1 || B == 1 || !blocks_fit) {
         for (int b = 0; b < B; ++b) NMGP_TRY(one_by_one(b));
         return 0;
     }

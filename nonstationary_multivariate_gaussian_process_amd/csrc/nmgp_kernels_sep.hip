@@ -89,9 +89,21 @@ __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__
     const double sigma2 = sm[M + M * M];
     const double xi = x[i], li = eb[i], si = sb[i];
     const double xi2 = xi * xi, li2 = li * li;
-    double* Sb = S + (size_t)b * M * bstride + i;
-    double* Kb = Kout ? Kout + (size_t)b * N * N + i : nullptr;
-#pragma unroll 2
+    // Buffer stores: one uniform descriptor per block (scalar registers) + ONE 32-bit byte offset per element, so that the address
+    // arithmetic of the M + 1 stores stays off the vector ALU -- which this kernel needs for the exp / sqrt / divisions (M = 5: one
+    // transcendental chain per 40 bytes stored; with flat 64-bit addresses a quarter of the loop's vector instructions were adds)
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    union D2 {
+        double d;
+        v2i_t v;
+    };
+    double* Sb = S + (size_t)b * M * bstride;
+    __amdgpu_buffer_rsrc_t rs[M];
+#pragma unroll
+    for (int p = 0; p < M; ++p) rs[p] = __builtin_amdgcn_make_buffer_rsrc((void*)(Sb + (size_t)p * bstride), 0, 0x7fffffff, 0x00020000);
+    const bool wantK = Kout != nullptr;
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(wantK ? Kout + (size_t)b * N * N : Sb), 0, 0x7fffffff, 0x00020000);
     for (int jj = 0; jj < TJ / 4; ++jj) {
         const int k = w * (TJ / 4) + jj;
         const int j = j0 + k;
@@ -102,13 +114,17 @@ __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__
         const double A = li2 + lj * lj;
         double v = (si * ss[k]) * sqrt(2.0 * (li * lj) / A) * exp(-dist / A);   // kernels.py:69-72
         if (i == j) v = NMGP_JITTER + v;
-        if (Kb) Kb[(size_t)j * N] = v;
-        const size_t col = (size_t)j * ldo;
+        D2 u;
+        if (wantK) {
+            u.d = v;
+            __builtin_amdgcn_raw_buffer_store_b64(u.v, rk, (j * N + i) * 8, 0, 0);
+        }
+        const int off = (j * ldo + i) * 8;                                       // bytes within a block: < 2^31 up to n = 16,383
+        const double dg = (i == j) ? sigma2 : 0.0;
 #pragma unroll
         for (int p = 0; p < M; ++p) {
-            double o = wB[p] * v;
-            if (i == j) o += sigma2;
-            Sb[(size_t)p * bstride + col] = o;
+            u.d = wB[p] * v + dg;
+            __builtin_amdgcn_raw_buffer_store_b64(u.v, rs[p], off, 0, 0);
         }
     }
 }
