@@ -877,6 +877,7 @@ extern "C" int nmgp_svc_batch_eval(nmgp_ctx* c, const double hyper[8], int prior
     const double* xs = multi ? c->b_x : c->d_x;
     const int xstride = multi ? N : 0;
     PriorFactor *pl = nullptr, *pL = nullptr;
+    // (the factor cache is a vector: the second look-up may grow it and move its elements, so the first pointer is re-resolved)
     if (multi) {
         NMGP_TRY(get_batch_prior(c, al_l, be_l, &pl));
         NMGP_TRY(get_batch_prior(c, al_L, be_L, &pL));
