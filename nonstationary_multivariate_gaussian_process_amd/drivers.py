@@ -329,6 +329,109 @@ def sampler(**kw):
 SVC_HYPER_KEYS = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_L", "alpha_L", "beta_L", "a", "b")
 
 
+def _randomized_eigs(hvp, P, k, rank, power_iters, lam_min, seed):
+    """Leading eigenpairs (by |eigenvalue|) of the symmetric operator behind ``hvp(V [k, P]) -> [k, P]`` (row v -> A v) by randomised
+    subspace iteration with k probes and ``power_iters`` extra passes.  Returns (U [r, P] orthonormal rows or None, lam [r] = |eig|,
+    info).  A NEGATIVE eigenvalue below -lam_min means the reference point is not a mode along that direction (an unconverged MAP
+    estimate, a saddle): it enters as |lam| (the SoftAbs rule), which keeps a leapfrog step stable while the chain leaves the region."""
+    def orth(Yv):
+        Q, _ = np.linalg.qr(Yv.T)
+        return np.ascontiguousarray(Q.T)
+
+    rng = np.random.default_rng(seed)
+    Yv = hvp(rng.standard_normal((k, P)))
+    for _ in range(int(power_iters)):
+        Yv = hvp(orth(Yv))
+    Q = orth(Yv)
+    AQ = hvp(Q)
+    Tm = AQ @ Q.T
+    asym = float(np.abs(Tm - Tm.T).max() / max(np.abs(Tm).max(), 1e-300))
+    ev, W = np.linalg.eigh(0.5 * (Tm + Tm.T))
+    order = np.argsort(-np.abs(ev))
+    ev, W = ev[order], W[:, order]
+    keep = np.flatnonzero(np.abs(ev[:rank]) > lam_min)
+    U = np.ascontiguousarray(W[:, keep].T @ Q) if keep.size else None
+    lam = np.ascontiguousarray(np.abs(ev[keep])) if keep.size else None
+    info = {"probes": int(k), "power_iters": int(power_iters), "kept": int(keep.size),
+            "lam_max": float(lam[0]) if keep.size else 0.0, "lam_min_kept": float(lam[-1]) if keep.size else 0.0,
+            "first_dropped": float(ev[keep.size]) if keep.size < ev.size else None,
+            "negative_kept": [float(v) for v in ev[keep] if v < 0], "most_negative": float(ev.min()),
+            "asymmetry_of_projected_hessian": asym, "eigenvalues": [float(v) for v in ev[:min(ev.size, rank + 8)]]}
+    return U, lam, info
+
+
+def _preconditioned_lbfgs(f, to_pars_factory, make_metric, q, maxiter, rounds, history, gtol, verbose, nev):
+    """The iteration behind :func:`polish_map` / :func:`polish_map_separable`: L-BFGS in whitened coordinates w (pars = q0 + L w, the
+    model's ``apply``), the initial matrix of the two-loop recursion H0 = (I + U diag(lam) U^T)^-1 from ``make_metric(q)`` (rebuilt
+    every maxiter / rounds iterations), Armijo backtracking.  ``f(w, to_pars) -> (NegLog, whitened gradient)`` (+inf, None outside the
+    domain); ``to_pars_factory(q0) -> to_pars(w)``; ``nev``: one-element evaluation counter shared with the caller."""
+    q_cur = q
+    P = q.shape[0]
+    per_round = max(1, int(np.ceil(maxiter / max(rounds, 1))))
+    fk = gn = None
+    for rnd in range(max(rounds, 1)):
+        met = make_metric(q_cur, rnd)
+        U, sc = (met.U, met.lam / (1.0 + met.lam)) if met.rank else (None, None)
+        to_pars = to_pars_factory(q_cur)
+
+        def precond(d):
+            return d - U.T @ (sc * (U @ d)) if U is not None else d
+
+        xk = np.zeros(P)
+        fk, gk = f(xk, to_pars)
+        if not np.isfinite(fk):
+            raise RuntimeError("polish: the objective is undefined at the start point")
+        S, Yv, rho = [], [], []
+        stalled = False
+        for _ in range(per_round):
+            gn = float(np.sqrt(_dot(gk, gk)))
+            if gn <= gtol * max(1.0, abs(fk)):
+                break
+            d = -gk.copy()
+            al = []
+            for s_, y_, r_ in zip(reversed(S), reversed(Yv), reversed(rho)):
+                a_ = r_ * _dot(s_, d)
+                al.append(a_)
+                d -= a_ * y_
+            d = precond(d)                               # H0 = (I + U lam U^T)^-1
+            for (s_, y_, r_), a_ in zip(zip(S, Yv, rho), reversed(al)):
+                d += (a_ - r_ * _dot(y_, d)) * s_
+            slope = _dot(gk, d)
+            if slope >= 0:                               # stale pairs: restart from the preconditioned gradient
+                S, Yv, rho = [], [], []
+                d = precond(-gk.copy())
+                slope = _dot(gk, d)
+            t = 1.0
+            while True:
+                xn = xk + t * d
+                fn, gnew = f(xn, to_pars)
+                if fn <= fk + 1e-4 * t * slope:
+                    break
+                t *= 0.5
+                if t < 1e-10:
+                    stalled = True
+                    break
+            if stalled:
+                break
+            s_, y_ = xn - xk, gnew - gk
+            sy = _dot(s_, y_)
+            if sy > 1e-10 * np.sqrt(_dot(s_, s_) * _dot(y_, y_)):
+                S.append(s_)
+                Yv.append(y_)
+                rho.append(1.0 / sy)
+                if len(S) > history:
+                    S.pop(0), Yv.pop(0), rho.pop(0)
+            xk, fk, gk = xn, fn, gnew
+        q_cur = to_pars(xk)
+        gn = float(np.sqrt(_dot(gk, gk)))
+        if verbose is not None:
+            verbose("polish round %d: NegLog %.4f, whitened |grad| %.3g, %d evaluations so far, metric rank %d (most negative %.3g)" % (
+                rnd, fk, gn, nev[0], met.rank, met.info["most_negative"]))
+        if gn <= gtol * max(1.0, abs(fk)):
+            break
+    return q_cur, fk, gn, nev[0]
+
+
 def _dot(a, b):
     # (not BLAS: on a 64-core host a threaded ddot of 14,337 elements costs more than the GPU evaluation it sits next to)
     return float(np.sum(a * b))
@@ -363,85 +466,27 @@ def polish_map(x, Y, hyper_pars, q, maxiter=300, ctx=None, history=30, gtol=1e-6
         buf[0] = v
         return ctx.svc_batch_prior_apply(hyper, buf, trans=trans)[0].copy()
 
-    per_round = max(1, int(np.ceil(maxiter / max(rounds, 1))))
-    fk = gn = None
-    for rnd in range(max(rounds, 1)):
-        met = prior_lowrank_metric(x, Y, hyper_pars, q_cur, rank=rank, oversample=max(B - rank, 0), power_iters=1, seed=11 + rnd, ctx=ctx,
+    def make_metric(q_at, rnd):
+        met = prior_lowrank_metric(x, Y, hyper_pars, q_at, rank=rank, oversample=max(B - rank, 0), power_iters=1, seed=11 + rnd, ctx=ctx,
                                    batch=B)          # (leaves a batch of B chains allocated: `apply` uses it)
         nev[0] += met.info["grad_evals"]
-        U, sc = (met.U, met.lam / (1.0 + met.lam)) if met.rank else (None, None)
-        q0 = q_cur
+        return met
 
-        def to_pars(w):
-            return q0 + apply(w, False)
+    def to_pars_factory(q0):
+        return lambda w: q0 + apply(w, False)
 
-        def f(w):
-            nev[0] += 1
-            try:
-                out, g = ctx.logpos_svc(to_pars(w), hyper, True, True)
-            except _lib.NmgpNumericalError:
-                return np.inf, None
-            v = float(out[0])
-            if not (np.isfinite(v) and np.all(np.isfinite(g))):
-                return np.inf, None
-            return v, apply(g, True)
+    def f(w, to_pars):
+        nev[0] += 1
+        try:
+            out, g = ctx.logpos_svc(to_pars(w), hyper, True, True)
+        except _lib.NmgpNumericalError:
+            return np.inf, None
+        v = float(out[0])
+        if not (np.isfinite(v) and np.all(np.isfinite(g))):
+            return np.inf, None
+        return v, apply(g, True)
 
-        xk = np.zeros(P)
-        fk, gk = f(xk)
-        if not np.isfinite(fk):
-            raise RuntimeError("polish_map: the objective is undefined at the start point")
-        S, Yv, rho = [], [], []
-        stalled = False
-        for _ in range(per_round):
-            gn = float(np.sqrt(_dot(gk, gk)))
-            if gn <= gtol * max(1.0, abs(fk)):
-                break
-            d = -gk.copy()
-            al = []
-            for s_, y_, r_ in zip(reversed(S), reversed(Yv), reversed(rho)):
-                a_ = r_ * _dot(s_, d)
-                al.append(a_)
-                d -= a_ * y_
-            if U is not None:
-                d -= U.T @ (sc * (U @ d))                # H0 = (I + U lam U^T)^-1
-            for (s_, y_, r_), a_ in zip(zip(S, Yv, rho), reversed(al)):
-                d += (a_ - r_ * _dot(y_, d)) * s_
-            slope = _dot(gk, d)
-            if slope >= 0:                               # stale pairs: restart from the preconditioned gradient
-                S, Yv, rho = [], [], []
-                d = -gk.copy()
-                if U is not None:
-                    d -= U.T @ (sc * (U @ d))
-                slope = _dot(gk, d)
-            t = 1.0
-            while True:
-                xn = xk + t * d
-                fn, gnew = f(xn)
-                if fn <= fk + 1e-4 * t * slope:
-                    break
-                t *= 0.5
-                if t < 1e-10:
-                    stalled = True
-                    break
-            if stalled:
-                break
-            s_, y_ = xn - xk, gnew - gk
-            sy = _dot(s_, y_)
-            if sy > 1e-10 * np.sqrt(_dot(s_, s_) * _dot(y_, y_)):
-                S.append(s_)
-                Yv.append(y_)
-                rho.append(1.0 / sy)
-                if len(S) > history:
-                    S.pop(0), Yv.pop(0), rho.pop(0)
-            xk, fk, gk = xn, fn, gnew
-        q_cur = to_pars(xk)
-        gn = float(np.sqrt(_dot(gk, gk)))
-        if verbose is not None:
-            verbose("polish round %d: NegLog %.4f, whitened |grad| %.3g, %d evaluations so far, metric rank %d (most negative %.3g)" % (
-                rnd, fk, gn, nev[0], met.rank, met.info["most_negative"]))
-        if gn <= gtol * max(1.0, abs(fk)):
-            break
-    return q_cur, fk, gn, nev[0]
+    return _preconditioned_lbfgs(f, to_pars_factory, make_metric, q_cur, maxiter, rounds, history, gtol, verbose, nev)
 
 
 class PriorMetric:
@@ -537,33 +582,152 @@ def prior_lowrank_metric(x, Y, hyper_pars, q_ref, rank=96, oversample=32, power_
         Hq = (Gp - Gm) / (2.0 * t[:, None])
         return in_chunks(Hq, lambda g: ctx.svc_batch_prior_apply(hyper, g, trans=True))
 
-    def orth(Yv):
-        Q, _ = np.linalg.qr(Yv.T)
-        return np.ascontiguousarray(Q.T)
+    U, lam, info = _randomized_eigs(hvp, P, k, rank, power_iters, lam_min, seed)
+    info.update(h=float(h), grad_evals=int(n_grad[0]))
+    return PriorMetric(hyper_pars, U, lam, info)
 
-    rng = np.random.default_rng(seed)
-    Yv = hvp(rng.standard_normal((k, P)))
-    for _ in range(int(power_iters)):
-        Yv = hvp(orth(Yv))
-    Q = orth(Yv)
-    AQ = hvp(Q)
-    Tm = AQ @ Q.T
-    asym = float(np.abs(Tm - Tm.T).max() / max(np.abs(Tm).max(), 1e-300))
-    ev, W = np.linalg.eigh(0.5 * (Tm + Tm.T))
-    # Largest |eigenvalue| first.  A NEGATIVE eigenvalue below -lam_min means q_ref is not a mode along that direction (an
-    # unconverged MAP estimate, a saddle): the metric takes |lam| there (the SoftAbs rule), which keeps the leapfrog step stable
-    # while the chain leaves the region; the direction's true scale is then found by the sampler, not by the metric.
-    order = np.argsort(-np.abs(ev))
-    ev, W = ev[order], W[:, order]
-    keep = np.flatnonzero(np.abs(ev[:rank]) > lam_min)
-    U = np.ascontiguousarray(W[:, keep].T @ Q)
-    lam = np.ascontiguousarray(np.abs(ev[keep]))
-    info = {"probes": k, "power_iters": int(power_iters), "h": float(h), "grad_evals": int(n_grad[0]), "kept": int(keep.size),
-            "lam_max": float(lam[0]) if keep.size else 0.0, "lam_min_kept": float(lam[-1]) if keep.size else 0.0,
-            "first_dropped": float(ev[keep.size]) if keep.size < ev.size else None,
-            "negative_kept": [float(v) for v in ev[keep] if v < 0], "most_negative": float(ev.min()),
-            "asymmetry_of_projected_hessian": asym, "eigenvalues": [float(v) for v in ev[:min(ev.size, rank + 8)]]}
-    return PriorMetric(hyper_pars, U if keep.size else None, lam if keep.size else None, info)
+
+SEP_HYPER_KEYS = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma", "beta_tilde_sigma", "a", "b", "c")
+
+
+class SeparablePriorMetric:
+    """The prior-factor metric of the SEPARABLE model (logpos.py:216-296; sampler call Separable_model.py:209-210), host side: its
+    parameter vector [tilde_l (N) | tilde_sigma (N) | uL_vec (T) | tilde_sigma2_err] carries GP priors RBF(alpha, beta) + 1e-6 I on
+    tilde_l and tilde_sigma (logpos.py:271-281) and Normal(0, c) on uL_vec (:283), so
+        L_blk = blockdiag(chol Sigma_l, chol Sigma_sigma, c I_T, 1),     M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T
+    exactly as :class:`PriorMetric` for the nonseparable model.  P = 2N + T + 1 is small enough (8,208 at config 5's size) for the
+    two N x N triangular products of a leapfrog step to run on the host (one dgemm each for all chains, next to a 100 ms batched
+    evaluation on the GPU); the covariances come from the library (``nmgp_rbf_cov``), their factors from LAPACK on the host."""
+
+    def __init__(self, L_l, L_s, c, T, U=None, lam=None, info=None):
+        self.L_l, self.L_s, self.c, self.T = np.ascontiguousarray(L_l), np.ascontiguousarray(L_s), float(c), int(T)
+        # both orientations contiguous: the two products of a leapfrog step then are plain row-major GEMMs [B, N] x [N, N]
+        self.Lt_l = np.ascontiguousarray(self.L_l.T)
+        self.Lt_s = self.Lt_l if L_s is L_l else np.ascontiguousarray(self.L_s.T)
+        self.N = L_l.shape[0]
+        self.P = 2 * self.N + self.T + 1
+        self.U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
+        self.lam = None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)
+        self.info = info or {}
+
+    @property
+    def rank(self):
+        return 0 if self.U is None else int(self.U.shape[0])
+
+    def apply(self, v, trans):
+        """L_blk v (trans False) or L_blk^T v (trans True) for the rows of v [B, P]."""
+        N, T = self.N, self.T
+        out = np.empty_like(v)
+        out[:, :N] = np.ascontiguousarray(v[:, :N]) @ (self.L_l if trans else self.Lt_l)
+        out[:, N:2 * N] = np.ascontiguousarray(v[:, N:2 * N]) @ (self.L_s if trans else self.Lt_s)
+        out[:, 2 * N:2 * N + T] = self.c * v[:, 2 * N:2 * N + T]
+        out[:, -1] = v[:, -1]
+        return out
+
+    def _lowrank(self, u, w):
+        return u if self.U is None else u + ((u @ self.U.T) * w) @ self.U
+
+    def root(self, z):          # u = (I + U lam U^T)^1/2 z
+        return self._lowrank(z, None if self.U is None else np.sqrt(1.0 + self.lam) - 1.0)
+
+    def W(self, u):             # (I + U lam U^T)^-1 u
+        return self._lowrank(u, None if self.U is None else -self.lam / (1.0 + self.lam))
+
+    def kinetic(self, u):
+        k = (u * u).sum(1)
+        if self.U is not None:
+            c = u @ self.U.T
+            k = k - (c * c * (self.lam / (1.0 + self.lam))).sum(1)
+        return 0.5 * k
+
+
+def separable_prior_metric(x, Y, hyper_pars, q_ref, rank=64, oversample=32, power_iters=1, h=1e-3, lam_min=0.5, seed=0, ctx=None,
+                           batch=16, factors=None):
+    """:class:`SeparablePriorMetric` of one subject at ``q_ref``: the GP-prior factors (computed once on the device; pass a previous
+    metric as ``factors`` to reuse them) and the leading eigenpairs of L_blk^T Hess(-loglik) L_blk by randomised subspace iteration
+    on central differences of the likelihood gradient, ``batch`` chains per ``nmgp_sep_batch_eval``."""
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    hyper = np.array([float(hyper_pars[k]) for k in SEP_HYPER_KEYS])
+    q_ref = np.asarray(q_ref, dtype=np.float64).reshape(-1)
+    N, M = Y.shape
+    T = M * (M + 1) // 2
+    P = 2 * N + T + 1
+    if q_ref.shape[0] != P:
+        raise ValueError("q_ref must have 2N + T + 1 = %d entries" % P)
+    ctx.set_data(x, Y)
+    if factors is not None:
+        L_l, L_s = factors.L_l, factors.L_s
+    else:
+        # covariance on the device (nmgp_rbf_cov: the reference's expression, kernels.py:24-43), factorisation by LAPACK on the host:
+        # a preconditioner's factor only has to be A factor of that matrix, and RBF + 1e-6 I at N = 4096 (condition number > 1e11) is
+        # beyond the panel solve of the library's general-purpose nmgp_cholesky entry (the objective's own cached prior factors
+        # take the substitution-based path)
+        L_l = np.linalg.cholesky(ctx.rbf_cov(x[:, None], None, hyper[1], hyper[2]))
+        L_s = L_l if (hyper[4], hyper[5]) == (hyper[1], hyper[2]) else np.linalg.cholesky(ctx.rbf_cov(x[:, None], None, hyper[4], hyper[5]))
+    # Normal(0, c) sees a float32-rounded c in the reference (logpos.py:283 passes a Python number to torch.distributions.Normal)
+    met = SeparablePriorMetric(L_l, L_s, float(np.float32(hyper[8])), T)
+    k = int(min(rank + oversample, P))
+    n_grad = [0]
+
+    def lik_grad(Q):
+        G = np.empty_like(Q)
+        for a in range(0, Q.shape[0], batch):
+            out, g, st = ctx.sep_batch_eval(Q[a:a + batch], hyper, False, True)
+            if (st != 0).any() or not np.all(np.isfinite(out[:, 1])):
+                raise RuntimeError("separable_prior_metric: the likelihood is undefined (or needed jitter) at a probe point: reduce h")
+            G[a:a + batch] = g
+        n_grad[0] += Q.shape[0]
+        return G
+
+    def hvp(V):
+        D = met.apply(V, False)
+        t = h / np.maximum(np.abs(D).max(1), 1e-300)
+        Hq = (lik_grad(q_ref[None] + t[:, None] * D) - lik_grad(q_ref[None] - t[:, None] * D)) / (2.0 * t[:, None])
+        return met.apply(Hq, True)
+
+    met.U, met.lam, info = _randomized_eigs(hvp, P, k, rank, power_iters, lam_min, seed)
+    info.update(h=float(h), grad_evals=int(n_grad[0]))
+    met.info = info
+    return met
+
+
+def polish_map_separable(x, Y, hyper_pars, q, maxiter=300, ctx=None, history=30, gtol=1e-6, rounds=4, rank=64, probes=96, batch=16,
+                         verbose=None):
+    """:func:`polish_map` for the separable objective (``logpos.nlogpos_obj``): metric-preconditioned L-BFGS in the whitened
+    coordinates of :class:`SeparablePriorMetric`.  Returns (pars, NegLog, whitened gradient norm, evaluations incl. the metric's)."""
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    hyper = np.array([float(hyper_pars[k]) for k in SEP_HYPER_KEYS])
+    x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    ctx.set_data(x, Y)
+    nev = [0]
+    q_cur = np.array(q, dtype=np.float64, copy=True).reshape(-1)
+    state = {"met": None}
+
+    def make_metric(q_at, rnd):
+        met = separable_prior_metric(x, Y, hyper_pars, q_at, rank=rank, oversample=max(probes - rank, 0), power_iters=1, seed=11 + rnd,
+                                     ctx=ctx, batch=batch, factors=state["met"])
+        nev[0] += met.info["grad_evals"]
+        state["met"] = met
+        return met
+
+    def to_pars_factory(q0):
+        return lambda w: q0 + state["met"].apply(w[None], False)[0]
+
+    def f(w, to_pars):
+        nev[0] += 1
+        try:
+            out, g = ctx.logpos_sep(to_pars(w), hyper, True, True)
+        except _lib.NmgpNumericalError:
+            return np.inf, None
+        v = float(out[0])
+        if not (np.isfinite(v) and np.all(np.isfinite(g))):
+            return np.inf, None
+        return v, state["met"].apply(g[None], True)[0]
+
+    return _preconditioned_lbfgs(f, to_pars_factory, make_metric, q_cur, maxiter, rounds, history, gtol, verbose, nev)
 
 
 class LockStepHMC:
@@ -599,6 +763,12 @@ class LockStepHMC:
             self.mass_kind = 3
             self.metric = M
             return
+        if isinstance(M, SeparablePriorMetric):
+            if M.P != P:
+                raise ValueError("the metric belongs to a parameter vector of length %d, not %d" % (M.P, P))
+            self.mass_kind = 4           # host-side whitened-momentum loop of BatchedHMCSeparable
+            self.metric = M
+            return
         if M is None:
             Minv = np.asarray(Minv, dtype=np.float64)
             M = 1.0 / Minv if Minv.ndim == 1 else np.linalg.inv(Minv)
@@ -621,15 +791,15 @@ class LockStepHMC:
         z = np.stack([r.standard_normal(self.P) for r in self.rngs])
         if self.mass_kind == 0:
             return z
-        if self.mass_kind == 3:
-            raise NotImplementedError("a PriorMetric runs in BatchedHMC's device-resident loop only")
+        if self.mass_kind >= 3:
+            raise NotImplementedError("a PriorMetric / SeparablePriorMetric runs in its sampler's own whitened-momentum loop")
         return z * self.Mchol if self.mass_kind == 1 else z @ self.Mchol.T
 
     def velocity(self, p):
         if self.mass_kind == 0:
             return p
-        if self.mass_kind == 3:
-            raise NotImplementedError("a PriorMetric runs in BatchedHMC's device-resident loop only")
+        if self.mass_kind >= 3:
+            raise NotImplementedError("a PriorMetric / SeparablePriorMetric runs in its sampler's own whitened-momentum loop")
         return p * self.Minv if self.mass_kind == 1 else p @ self.Minv          # (M^-1 is symmetric)
 
     def kinetic(self, p):
@@ -799,13 +969,18 @@ class BatchedHMCSeparable(LockStepHMC):
     ``logpos.nlogpos_obj`` and its gradient for all chains with one launch sequence (``nmgp_sep_batch_eval``: the chains' B*M
     blocks ``wB[p] K_x + sigma2 I`` form one batch of the blocked Cholesky).  The sampler call of ``Separable_model.py:209`` /
     ``Separable_model_mpiKAISER.py:281`` for B chains at once; chain b reproduces ``HMCSampler(potential_func=logpos.nlogpos_obj,
-    ...)`` started from the same state with the same random stream.  The leapfrog update runs on the host (P = 2N + T + 1)."""
+    ...)`` started from the same state with the same random stream.  The leapfrog update runs on the host (P = 2N + T + 1).
+    ``M=`` a :class:`SeparablePriorMetric` (from :func:`separable_prior_metric`) selects the whitened-momentum loop -- the metric
+    under which this model's chains mix; ``step_jitter`` as in :class:`BatchedHMC`."""
 
-    KEYS = ("mu_tilde_l", "alpha_tilde_l", "beta_tilde_l", "mu_tilde_sigma", "alpha_tilde_sigma", "beta_tilde_sigma", "a", "b", "c")
+    KEYS = SEP_HYPER_KEYS
 
-    def __init__(self, x, Y, hyper_pars, init_positions, step_size=2e-4, num_steps_in_leap=20, seed=None, ctx=None, M=None, Minv=None):
+    def __init__(self, x, Y, hyper_pars, init_positions, step_size=2e-4, num_steps_in_leap=20, seed=None, ctx=None, M=None, Minv=None,
+                 step_jitter=0.0):
         from . import _lib
         super().__init__(init_positions, step_size, num_steps_in_leap, seed, M, Minv)
+        self.step_jitter = float(step_jitter)
+        self.jitter_rng = np.random.default_rng(None if seed is None else 7919 * (seed + 1))
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.hyper = np.array([float(hyper_pars[k]) for k in self.KEYS])
         self.ctx.set_data(np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64))
@@ -818,3 +993,43 @@ class BatchedHMCSeparable(LockStepHMC):
         U[bad] = np.inf
         g[bad] = 0.0
         return U, g
+
+    def run(self, sample_size):
+        """With ``M=`` a :class:`SeparablePriorMetric` the chains carry the whitened momentum u = L_blk^T p (as the device-resident
+        nonseparable sampler does): draw u = (I + U lam U^T)^1/2 z, kick u -= c L_blk^T g, drift q += eps L_blk (I + U lam U^T)^-1 u,
+        kinetic energy 1/2 u^T (I + U lam U^T)^-1 u -- triangular PRODUCTS with the prior factors only, on the host, around one
+        batched evaluation on the GPU per leapfrog step.  Any other mass matrix: the lock-step loop of the base class."""
+        if self.mass_kind != 4:
+            return super().run(sample_size)
+        met = self.metric
+        B, P = self.B, self.P
+        samples = np.zeros((sample_size, B, P))
+        U, g = self.potential_and_grad(self.q)
+        accepted = np.zeros(B)
+        energy_err = np.zeros((sample_size, B))
+        for it in range(sample_size):
+            eps = self.eps if self.step_jitter <= 0 else self.eps * (1.0 + self.step_jitter * self.jitter_rng.uniform(-1.0, 1.0))
+            z = np.stack([r.standard_normal(P) for r in self.rngs])
+            H0 = U + 0.5 * (z * z).sum(1)
+            q1 = self.q.copy()
+            u1 = met.root(z) - 0.5 * eps * met.apply(g, True)
+            U1, g1 = U, g
+            failed = np.zeros(B, dtype=bool)
+            for step in range(self.L):
+                q1 = q1 + eps * met.apply(met.W(u1), False)
+                U1, g1 = self.potential_and_grad(q1)
+                failed |= ~np.isfinite(U1)
+                u1 = u1 - (eps if step < self.L - 1 else 0.5 * eps) * met.apply(g1, True)
+            U1 = np.where(failed, np.inf, U1)
+            H1 = U1 + met.kinetic(u1)
+            with np.errstate(invalid="ignore"):
+                dH = H1 - H0
+            lu = np.array([np.log(r.random()) for r in self.rngs])
+            acc = np.isfinite(dH) & (lu < -dH)
+            self.q[acc] = q1[acc]
+            U = np.where(acc, U1, U)
+            g = np.where(acc[:, None], g1, g)
+            accepted += acc
+            energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
+            samples[it] = self.q
+        return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}

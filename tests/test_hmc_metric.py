@@ -360,3 +360,85 @@ def test_metric_preconditioned_lbfgs_reaches_the_mode_where_adam_does_not():
     assert gna < 1e-5 * abs(nla) + 1e-3 and gnb < 1e-5 * abs(nlb) + 1e-3
     met = prior_lowrank_metric(d["x"], d["Y"], h, qa, rank=32, oversample=8, seed=2, batch=8)
     assert met.info["most_negative"] > -0.9                               # I + A positive definite: a mode, not a saddle
+
+
+def test_separable_prior_metric_algebra_cpu():
+    """SeparablePriorMetric on the host: root(z) has covariance I + U lam U^T, W is its inverse, the kinetic energy of root(z) is
+    1/2 |z|^2, and apply / apply^T are the block products with the factors they were given."""
+    from nonstationary_multivariate_gaussian_process_amd.drivers import SeparablePriorMetric
+    rng = np.random.default_rng(0)
+    N, T, r, B = 7, 3, 4, 5
+    P = 2 * N + T + 1
+    L_l = np.tril(rng.standard_normal((N, N))) + 3 * np.eye(N)
+    L_s = np.tril(rng.standard_normal((N, N))) + 3 * np.eye(N)
+    Q, _ = np.linalg.qr(rng.standard_normal((P, r)))
+    lam = np.array([50.0, 7.0, 1.5, 0.6])
+    met = SeparablePriorMetric(L_l, L_s, 10.0, T, Q.T, lam)
+    Lb = np.zeros((P, P))
+    Lb[:N, :N], Lb[N:2 * N, N:2 * N] = L_l, L_s
+    Lb[2 * N:2 * N + T, 2 * N:2 * N + T] = 10.0 * np.eye(T)
+    Lb[-1, -1] = 1.0
+    v = rng.standard_normal((B, P))
+    assert np.allclose(met.apply(v, False), v @ Lb.T) and np.allclose(met.apply(v, True), v @ Lb)
+    H = np.eye(P) + Q @ np.diag(lam) @ Q.T
+    Rm = np.stack([met.root(e) for e in np.eye(P)[None]])[0]                     # rows: root(e_k)
+    assert np.allclose(Rm @ Rm.T, H) and np.allclose(met.W(v) @ H, v)
+    assert np.allclose(met.kinetic(met.root(v)), 0.5 * (v * v).sum(1))
+    assert np.allclose(met.kinetic(v), 0.5 * np.einsum("bi,ij,bj->b", v, np.linalg.inv(H), v))
+    plain = SeparablePriorMetric(L_l, L_s, 10.0, T)
+    assert plain.rank == 0 and np.array_equal(plain.root(v), v) and np.array_equal(plain.W(v), v)
+
+
+@pytest.mark.gpu
+def test_separable_sampler_under_its_prior_metric_mixes_and_agrees_with_the_dense_mass_loop():
+    """The separable model's sampler call (Separable_model.py:209-210) for B chains, the recipe of tools/hmc_sep.py: mode by
+    metric-preconditioned L-BFGS (polish_map_separable), SeparablePriorMetric there, a warm-up, the metric REBUILT at the chains'
+    mean (this posterior's mass sits far from its mode along the sigma(x) <-> B scale ridge: the mode's curvature is not the typical
+    set's), then the whitened-momentum loop of BatchedHMCSeparable -- against the base class's lock-step loop with the SAME metric
+    written out as a dense mass matrix (posterior summaries within Monte-Carlo error), and against the identity mass at the same
+    cost (which does not mix)."""
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from nonstationary_multivariate_gaussian_process_amd.drivers import BatchedHMCSeparable, polish_map_separable, separable_prior_metric
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hmc_1000 as H
+    N, M = 64, 3
+    d = sim.simulate_separable(N, M, 4)
+    h = dict(sim.HYPER_SEP)
+    p0 = sim.perturb(d["pars_true"], 0.05, 0.4)
+    q0, nl, gn, nev = polish_map_separable(d["x"], d["Y"], h, p0, maxiter=400, rounds=8, probes=40, rank=32, batch=8)
+    assert gn < 1e-5 * abs(nl) + 1e-3
+    P = q0.shape[0]
+    met = separable_prior_metric(d["x"], d["Y"], h, q0, rank=32, oversample=8, seed=3, batch=8)
+    assert met.info["most_negative"] > -0.9 and met.rank >= 4
+    B, L = 8, 10
+    init = np.repeat(q0[None], B, 0)
+    sw, iw = BatchedHMCSeparable(d["x"], d["Y"], h, init, step_size=0.06, num_steps_in_leap=20, seed=40, M=met, step_jitter=0.2).run(400)
+    assert iw["accept_rate"].mean() > 0.6
+    cur = sw[-1]
+    for wdw in range(2):                                     # two adaptation windows
+        met = separable_prior_metric(d["x"], d["Y"], h, sw[-100:].mean((0, 1)), rank=32, oversample=8, seed=5 + wdw, batch=8, factors=met)
+        assert met.info["most_negative"] > -0.9
+        sw, iw = BatchedHMCSeparable(d["x"], d["Y"], h, cur, step_size=0.15, num_steps_in_leap=L, seed=50 + wdw, M=met, step_jitter=0.2).run(400)
+        cur = sw[-1]
+    assert iw["accept_rate"].mean() > 0.8
+    a = sw[200:]
+    rh = H.split_rhat(a)
+    assert np.nanmedian(rh) < 1.05 and np.nanquantile(rh, 0.99) < 1.2
+    # the same metric as a dense matrix through the base class's loop (momenta p = chol(M) z, velocity M^-1 p), from the same positions
+    Lb = met.apply(np.eye(P), False).T
+    Wm = np.eye(P) - met.U.T @ np.diag(met.lam / (1 + met.lam)) @ met.U
+    Minv = Lb @ Wm @ Lb.T
+    Minv = 0.5 * (Minv + Minv.T)
+    sdn, idn = BatchedHMCSeparable(d["x"], d["Y"], h, cur, step_size=0.15, num_steps_in_leap=L, seed=77, Minv=Minv).run(400)
+    assert abs(idn["accept_rate"].mean() - iw["accept_rate"].mean()) < 0.12
+    b = sdn[200:]
+    for i in (P - 1, 0, N // 2, N + 5, 2 * N, 2 * N + 1):
+        ma, mb = a[:, :, i].mean(), b[:, :, i].mean()
+        sd = 0.5 * (a[:, :, i].std() + b[:, :, i].std())
+        ess = min(H.multichain_ess(a[:, :, [i]])[0], H.multichain_ess(b[:, :, [i]])[0])
+        assert abs(ma - mb) < 5.0 * sd * np.sqrt(2.0 / max(ess, 10.0)), (i, ma, mb, sd, ess)
+    # the posterior's mass is far from its mode (what the adaptation windows are for): log-diagonal of L
+    assert a[:, :, 2 * N].mean() - q0[2 * N] > 3.0 * a[:, :, 2 * N].std()
+    si, ii = BatchedHMCSeparable(d["x"], d["Y"], h, init, step_size=2e-4, num_steps_in_leap=L, seed=40).run(400)
+    assert np.nanmedian(H.split_rhat(si[200:])) > 1.5
