@@ -154,6 +154,11 @@ int nmgp_svc_batch_traj_set_mass(nmgp_ctx* ctx, int kind, const double* minv);
 int nmgp_svc_batch_traj_set_mass_chol(nmgp_ctx* ctx, int kind, const double* mchol);
 int nmgp_svc_batch_traj_set_mass_prior(nmgp_ctx* ctx, const double hyper[8], int rank, const double* U, const double* lam);
 int nmgp_svc_batch_prior_apply(nmgp_ctx* ctx, const double hyper[8], int trans, const double* in, double* out);
+/* The same change of coordinates for the SEPARABLE model's parameter vector [tilde_l | tilde_sigma | uL_vec | tilde_sigma2_err]:
+ * L_blk = blockdiag(chol Sigma_l, chol Sigma_sigma, c I_T, 1) -- the GP priors of logpos.py:271-281 and the Normal(0, c) prior of
+ * :283 (c float32-rounded, as the reference passes it); hyper as for nmgp_logpos_sep.  in / out: B host vectors of length 2N+T+1.
+ * The metric of the separable sampler (drivers.SeparablePriorMetric) is built on it. */
+int nmgp_sep_prior_apply(nmgp_ctx* ctx, const double hyper[9], int trans, int B, const double* in, double* out);
 int nmgp_svc_batch_traj(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* p0,
                         double* q1, double* p1, double* U1, int* failed);
 int nmgp_svc_batch_traj_z(nmgp_ctx* ctx, const double hyper[8], int prior, double eps, int nsteps, const double* z,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "nmgp_svc_batch_traj_commit": (I, [V, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_traj_set_mass_prior": (I, [V, P, I, P, P]),
     "nmgp_svc_batch_prior_apply": (I, [V, P, I, P, P]),
+    "nmgp_sep_prior_apply": (I, [V, P, I, I, P, P]),
     "nmgp_svc_batch_adam_begin": (I, [V]),
     "nmgp_svc_batch_adam_step": (I, [V, P, I, D, D, D, D, P, ctypes.POINTER(ctypes.c_int)]),
     "nmgp_svc_batch_get_pars": (I, [V, P]),
@@ -335,6 +336,17 @@ class Context:
             raise NmgpError("v must be [B=%d, P=%d], got %s" % (self.B, P_, v.shape))
         out = np.empty_like(v)
         self.check(self.lib.nmgp_svc_batch_prior_apply(self.h, ptr(hyper), int(bool(trans)), ptr(v), ptr(out)))
+        return out
+
+    def sep_prior_apply(self, hyper, v, trans=False):
+        """L_blk v / L_blk^T v for B vectors v [B, 2N+T+1] of the SEPARABLE parameter layout: L_blk = blockdiag(chol Sigma_l,
+        chol Sigma_sigma, c I_T, 1) from the cached GP-prior factors named by hyper [9]."""
+        hyper, v = as_f64(hyper), as_f64(v)
+        P_ = 2 * self.N + self.T + 1
+        if v.ndim != 2 or v.shape[1] != P_:
+            raise NmgpError("v must be [B, 2N+T+1 = %d], got %s" % (P_, v.shape))
+        out = np.empty_like(v)
+        self.check(self.lib.nmgp_sep_prior_apply(self.h, ptr(hyper), int(bool(trans)), int(v.shape[0]), ptr(v), ptr(out)))
         return out
 
     def svc_batch_traj_z(self, hyper, prior, eps, nsteps, z):

@@ -1285,6 +1285,32 @@ extern "C" int nmgp_svc_batch_prior_apply(nmgp_ctx* c, const double hyper[8], in
     return nmgp_take_launch_error(c);
 }
 
+// The same change of coordinates for the SEPARABLE model's parameter vector [tilde_l | tilde_sigma | uL_vec | tilde_sigma2_err]
+// (logpos.py:17-29): L_blk = blockdiag(chol Sigma_l, chol Sigma_sigma, c I_T, 1) with the cached factors of the GP priors of
+// logpos.py:271-281 and the (float32-rounded, as the reference passes it) sd c of the Normal(0, c) prior on uL_vec (:283).
+// in / out: B vectors of length 2N + T + 1 (host).  The resident subject's factors; no batch has to be allocated.
+extern "C" int nmgp_sep_prior_apply(nmgp_ctx* c, const double hyper[9], int trans, int B, const double* in, double* out) {
+    if (!c) return NMGP_E_NULL;
+    if (!hyper || !in || !out) return nmgp_fail(c, NMGP_E_NULL, "NULL argument");
+    if (!c->d_x) return nmgp_fail(c, NMGP_E_STATE, "nmgp_set_data must be called first");
+    if (B <= 0) return nmgp_fail(c, NMGP_E_SHAPE, "B must be positive");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->N, T = c->T;
+    const size_t P = (size_t)2 * N + T + 1;
+    PriorFactor *pl = nullptr, *ps = nullptr;
+    NMGP_TRY(nmgp_get_prior(c, hyper[1], hyper[2], &pl));
+    NMGP_TRY(nmgp_get_prior(c, hyper[4], hyper[5], &ps));
+    NMGP_TRY(nmgp_get_prior(c, hyper[1], hyper[2], &pl));      // (re-resolved: the second look-up may have grown the cache)
+    double *din = nullptr, *dout = nullptr;
+    NMGP_TRY(nmgp_scratch_get(c, 3, (size_t)B * P, &din));
+    NMGP_TRY(nmgp_scratch_get(c, 4, (size_t)B * P, &dout));
+    HIP_TRY(c, hipMemcpyAsync(din, in, (size_t)B * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    prior_trmm_sep(c->stream, trans != 0, pl->L, pl->ld, ps->L, ps->ld, din, dout, N, T, (long long)P, B, (double)(float)hyper[8]);
+    HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)B * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return nmgp_take_launch_error(c);
+}
+
 // The leapfrog loop shared by nmgp_svc_batch_traj / nmgp_svc_batch_traj_z: the momenta are in b_mom.  ANY API-level failure in
 // the middle of a trajectory (an evaluation, a library GEMM of the dense-mass drift -- not a chain's numerical failure: those
 // are flags) goes through ONE block that puts the start state back and demands a fresh value+gradient evaluation before the next

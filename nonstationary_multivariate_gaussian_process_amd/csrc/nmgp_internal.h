@@ -307,6 +307,8 @@ void hmc_restore(hipStream_t s, double* q, double* g, const double* q0, const do
 // out[b] (op)= coef * op(L_blk) in[b] over the parameter layout (mode 0 assign, 1 out += coef acc, 2 out -= coef acc unless bad[b])
 void prior_trmm(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
                 const double* in, double* out, int N, int T, long long P, int B, int cps, double coef, int mode, const int* bad);
+void prior_trmm_sep(hipStream_t s, bool trans, const double* L0, int ld0, const double* L1, int ld1, const double* in, double* out, int N,
+                    int T, long long P, int B, double cscale);
 void lowrank_proj(hipStream_t s, const double* U, const double* u, double* c, long long P, int r, int B, int cps);
 void lowrank_apply(hipStream_t s, const double* U, const double* wgt, const double* c, const double* in, double* out, long long P,
                    int r, int B, int cps);

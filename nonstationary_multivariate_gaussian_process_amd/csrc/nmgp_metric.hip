@@ -31,11 +31,15 @@ static inline int cdiv_m(long long a, long long b) { return (int)((a + b - 1) / 
 // grid (ceil(N / 64), B, 1 + ceil(T / TRMM_CG)): blockIdx.z = 0 is block 0, z >= 1 the column group z - 1 of blocks 1..T.
 // A workgroup owns 64 rows i; it walks the factor tiles of its row (k <= i, or k >= i for the transpose), staging each 64 x 64 tile
 // through LDS so that both orientations read HBM/L2 along the contiguous index and compute with lanes along i.
-template <bool TRANS>
+// LAYOUT 0: the nonseparable parameter vector (above).  LAYOUT 1: the SEPARABLE one, [tilde_l (N) | tilde_sigma (N) | uL_vec (T) |
+// tilde_sigma2_err] (logpos.py:17-29): two contiguous blocks with factors L0 / L1 (grid.z = 2), the T entries of uL_vec scaled by
+// `cscale` (the sd of their Normal(0, c) prior, logpos.py:283), the last entry unchanged.
+template <bool TRANS, int LAYOUT>
 __global__ __launch_bounds__(256) void k_prior_trmm(const double* __restrict__ L0, int ld0, long long s0,
                                                      const double* __restrict__ L1, int ld1, long long s1,
                                                      const double* __restrict__ in, double* __restrict__ out, int N, int T,
-                                                     long long P, int cps, double coef, int mode, const int* __restrict__ bad) {
+                                                     long long P, int cps, double coef, int mode, const int* __restrict__ bad,
+                                                     double cscale) {
     __shared__ double Lt[64 * 65];               // Lt[k * 65 + i] = op(L)[i0 + i, kb + k]
     __shared__ double vin[TRMM_CG][64];
     __shared__ double red[4][TRMM_CG][64];
@@ -45,8 +49,8 @@ __global__ __launch_bounds__(256) void k_prior_trmm(const double* __restrict__ L
     const int subj = b / cps;
     const double* L = zg == 0 ? L0 + (size_t)subj * s0 : L1 + (size_t)subj * s1;
     const int ld = zg == 0 ? ld0 : ld1;
-    const int j0 = zg == 0 ? 0 : 1 + (zg - 1) * TRMM_CG;                 // first prior block of this workgroup
-    const int nc = zg == 0 ? 1 : (T - (zg - 1) * TRMM_CG < TRMM_CG ? T - (zg - 1) * TRMM_CG : TRMM_CG);
+    const int j0 = (LAYOUT == 1) ? zg : (zg == 0 ? 0 : 1 + (zg - 1) * TRMM_CG);      // first prior block of this workgroup
+    const int nc = (LAYOUT == 1 || zg == 0) ? 1 : (T - (zg - 1) * TRMM_CG < TRMM_CG ? T - (zg - 1) * TRMM_CG : TRMM_CG);
     const double* inb = in + (size_t)b * P;
     double* outb = out + (size_t)b * P;
     const int i0 = ib * 64;
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(256) void k_prior_trmm(const double* __restrict__ L
             const int c = e & 63, j = e >> 6;
             const int k = kb + c;
             double v = 0.0;
-            if (j < nc && k < N) v = (j0 + j == 0) ? inb[k] : inb[(size_t)N + (size_t)k * T + (j0 + j - 1)];
+            if (j < nc && k < N)
+                v = (LAYOUT == 1) ? inb[(size_t)j0 * N + k] : ((j0 + j == 0) ? inb[k] : inb[(size_t)N + (size_t)k * T + (j0 + j - 1)]);
             vin[j][c] = v;
         }
         __syncthreads();
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void k_prior_trmm(const double* __restrict__ L
         const int i = i0 + r;
         if (j >= nc || i >= N) continue;
         const double v = ((red[0][j][r] + red[1][j][r]) + red[2][j][r]) + red[3][j][r];
-        const size_t o = (j0 + j == 0) ? (size_t)i : (size_t)N + (size_t)i * T + (j0 + j - 1);
+        const size_t o = (LAYOUT == 1) ? (size_t)j0 * N + i : ((j0 + j == 0) ? (size_t)i : (size_t)N + (size_t)i * T + (j0 + j - 1));
         if (mode == 0) outb[o] = v;
         else if (mode == 1) outb[o] = outb[o] + coef * v;
         else outb[o] = outb[o] - coef * v;
@@ -108,6 +113,13 @@ __global__ __launch_bounds__(256) void k_prior_trmm(const double* __restrict__ L
         else if (mode == 1) outb[P - 1] = outb[P - 1] + coef * v;
         else outb[P - 1] = outb[P - 1] - coef * v;
     }
+    if (LAYOUT == 1 && ib == 0 && zg == 0 && tid >= 64 && tid < 64 + T) {        // uL_vec: diagonal block cscale I
+        const size_t o = (size_t)2 * N + (tid - 64);
+        const double v = cscale * inb[o];
+        if (mode == 0) outb[o] = v;
+        else if (mode == 1) outb[o] = outb[o] + coef * v;
+        else outb[o] = outb[o] - coef * v;
+    }
 }
 
 void prior_trmm(hipStream_t s, bool trans, const double* L0, int ld0, long long s0, const double* L1, int ld1, long long s1,
@@ -115,9 +127,19 @@ void prior_trmm(hipStream_t s, bool trans, const double* L0, int ld0, long long 
     if (cps < 1) cps = 1;
     const dim3 grid(cdiv_m(N, 64), B, 1 + cdiv_m(T, TRMM_CG));
     if (trans)
-        NMGP_LAUNCH(k_prior_trmm<true>, grid, dim3(256), 0, s, L0, ld0, s0, L1, ld1, s1, in, out, N, T, P, cps, coef, mode, bad);
+        NMGP_LAUNCH((k_prior_trmm<true, 0>), grid, dim3(256), 0, s, L0, ld0, s0, L1, ld1, s1, in, out, N, T, P, cps, coef, mode, bad, 1.0);
     else
-        NMGP_LAUNCH(k_prior_trmm<false>, grid, dim3(256), 0, s, L0, ld0, s0, L1, ld1, s1, in, out, N, T, P, cps, coef, mode, bad);
+        NMGP_LAUNCH((k_prior_trmm<false, 0>), grid, dim3(256), 0, s, L0, ld0, s0, L1, ld1, s1, in, out, N, T, P, cps, coef, mode, bad, 1.0);
+}
+
+// the separable parameter layout: out = op(blockdiag(L0, L1, cscale I_T, 1)) in for B vectors of length P = 2N + T + 1 (mode 0)
+void prior_trmm_sep(hipStream_t s, bool trans, const double* L0, int ld0, const double* L1, int ld1, const double* in, double* out, int N,
+                    int T, long long P, int B, double cscale) {
+    const dim3 grid(cdiv_m(N, 64), B, 2);
+    if (trans)
+        NMGP_LAUNCH((k_prior_trmm<true, 1>), grid, dim3(256), 0, s, L0, ld0, 0LL, L1, ld1, 0LL, in, out, N, T, P, B, 1.0, 0, nullptr, cscale);
+    else
+        NMGP_LAUNCH((k_prior_trmm<false, 1>), grid, dim3(256), 0, s, L0, ld0, 0LL, L1, ld1, 0LL, in, out, N, T, P, B, 1.0, 0, nullptr, cscale);
 }
 
 // c[b, k] = sum_i U[subject(b)][k, i] u[b, i]   (U stored as r rows of length P per subject).  One workgroup per (k, chain): strided

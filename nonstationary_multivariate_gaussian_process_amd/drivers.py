@@ -596,15 +596,23 @@ class SeparablePriorMetric:
     tilde_l and tilde_sigma (logpos.py:271-281) and Normal(0, c) on uL_vec (:283), so
         L_blk = blockdiag(chol Sigma_l, chol Sigma_sigma, c I_T, 1),     M^-1 = L_blk (I + U diag(lam) U^T)^-1 L_blk^T
     exactly as :class:`PriorMetric` for the nonseparable model.  P = 2N + T + 1 is small enough (8,208 at config 5's size) for the
-    two N x N triangular products of a leapfrog step to run on the host (one dgemm each for all chains, next to a 100 ms batched
-    evaluation on the GPU); the covariances come from the library (``nmgp_rbf_cov``), their factors from LAPACK on the host."""
+    leapfrog update itself to stay on the host; its two triangular products per step run on the device with the context's cached
+    prior factors (``nmgp_sep_prior_apply``: the nonseparable sampler's ``k_prior_trmm`` with the separable parameter layout)."""
 
-    def __init__(self, L_l, L_s, c, T, U=None, lam=None, info=None):
-        self.L_l, self.L_s, self.c, self.T = np.ascontiguousarray(L_l), np.ascontiguousarray(L_s), float(c), int(T)
-        # both orientations contiguous: the two products of a leapfrog step then are plain row-major GEMMs [B, N] x [N, N]
-        self.Lt_l = np.ascontiguousarray(self.L_l.T)
-        self.Lt_s = self.Lt_l if L_s is L_l else np.ascontiguousarray(self.L_s.T)
-        self.N = L_l.shape[0]
+    def __init__(self, L_l, L_s, c, T, U=None, lam=None, info=None, ctx=None, hyper=None, N=None):
+        """Either the two factors as host matrices (``L_l``, ``L_s``; tests, or a caller with its own factors) or ``ctx`` + ``hyper``
+        [9] + ``N``: the products then run on the device with the context's cached prior factors (``nmgp_sep_prior_apply``)."""
+        self.ctx, self.hyper = ctx, (None if hyper is None else np.asarray(hyper, dtype=np.float64))
+        self.c, self.T = float(c), int(T)
+        if ctx is None:
+            self.L_l, self.L_s = np.ascontiguousarray(L_l), np.ascontiguousarray(L_s)
+            # both orientations contiguous: the two products of a leapfrog step then are plain row-major GEMMs [B, N] x [N, N]
+            self.Lt_l = np.ascontiguousarray(self.L_l.T)
+            self.Lt_s = self.Lt_l if L_s is L_l else np.ascontiguousarray(self.L_s.T)
+            self.N = self.L_l.shape[0]
+        else:
+            self.L_l = self.L_s = self.Lt_l = self.Lt_s = None
+            self.N = int(N)
         self.P = 2 * self.N + self.T + 1
         self.U = None if U is None else np.ascontiguousarray(U, dtype=np.float64)
         self.lam = None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)
@@ -616,6 +624,8 @@ class SeparablePriorMetric:
 
     def apply(self, v, trans):
         """L_blk v (trans False) or L_blk^T v (trans True) for the rows of v [B, P]."""
+        if self.ctx is not None:
+            return self.ctx.sep_prior_apply(self.hyper, np.ascontiguousarray(v), trans)
         N, T = self.N, self.T
         out = np.empty_like(v)
         out[:, :N] = np.ascontiguousarray(v[:, :N]) @ (self.L_l if trans else self.Lt_l)
@@ -643,9 +653,9 @@ class SeparablePriorMetric:
 
 def separable_prior_metric(x, Y, hyper_pars, q_ref, rank=64, oversample=32, power_iters=1, h=1e-3, lam_min=0.5, seed=0, ctx=None,
                            batch=16, factors=None):
-    """:class:`SeparablePriorMetric` of one subject at ``q_ref``: the GP-prior factors (computed once on the device; pass a previous
-    metric as ``factors`` to reuse them) and the leading eigenpairs of L_blk^T Hess(-loglik) L_blk by randomised subspace iteration
-    on central differences of the likelihood gradient, ``batch`` chains per ``nmgp_sep_batch_eval``."""
+    """:class:`SeparablePriorMetric` of one subject at ``q_ref``: the context's cached GP-prior factors (``factors`` is accepted for
+    compatibility and ignored) and the leading eigenpairs of L_blk^T Hess(-loglik) L_blk by randomised subspace iteration on central
+    differences of the likelihood gradient, ``batch`` chains per ``nmgp_sep_batch_eval``."""
     from . import _lib
     ctx = ctx if ctx is not None else _lib.default_context()
     x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
@@ -657,17 +667,8 @@ def separable_prior_metric(x, Y, hyper_pars, q_ref, rank=64, oversample=32, powe
     if q_ref.shape[0] != P:
         raise ValueError("q_ref must have 2N + T + 1 = %d entries" % P)
     ctx.set_data(x, Y)
-    if factors is not None:
-        L_l, L_s = factors.L_l, factors.L_s
-    else:
-        # covariance on the device (nmgp_rbf_cov: the reference's expression, kernels.py:24-43), factorisation by LAPACK on the host:
-        # a preconditioner's factor only has to be A factor of that matrix, and RBF + 1e-6 I at N = 4096 (condition number > 1e11) is
-        # beyond the panel solve of the library's general-purpose nmgp_cholesky entry (the objective's own cached prior factors
-        # take the substitution-based path)
-        L_l = np.linalg.cholesky(ctx.rbf_cov(x[:, None], None, hyper[1], hyper[2]))
-        L_s = L_l if (hyper[4], hyper[5]) == (hyper[1], hyper[2]) else np.linalg.cholesky(ctx.rbf_cov(x[:, None], None, hyper[4], hyper[5]))
     # Normal(0, c) sees a float32-rounded c in the reference (logpos.py:283 passes a Python number to torch.distributions.Normal)
-    met = SeparablePriorMetric(L_l, L_s, float(np.float32(hyper[8])), T)
+    met = SeparablePriorMetric(None, None, float(np.float32(hyper[8])), T, ctx=ctx, hyper=hyper, N=N)
     k = int(min(rank + oversample, P))
     n_grad = [0]
 

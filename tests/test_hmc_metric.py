@@ -108,6 +108,42 @@ def test_prior_apply_uses_each_subjects_own_factors():
         c.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,hv", [
+    (96, 3, [0.0, 10.0, 1.0, 0.0, 10.0, 1.0, 1.0, 1.0, 10.0]),     # the scripts' hyper-parameters: one factor for both GP blocks
+    (130, 2, [0.3, 5.0, 0.1, -0.2, 2.0, 0.2, 1.0, 1.0, 2.3025851]),   # two factors, ragged N, a c that float32 rounds
+])
+def test_separable_prior_apply_is_the_block_factor_of_the_separable_priors(N, M, hv):
+    """nmgp_sep_prior_apply: L_blk = blockdiag(chol Sigma_l, chol Sigma_sigma, c I_T, 1) on [tilde_l | tilde_sigma | uL_vec | s2]."""
+    from oracle import nmgp_oracle as O
+    from nonstationary_multivariate_gaussian_process_amd import _lib, sim
+    d = sim.simulate_separable(N, M, 4)
+    T = M * (M + 1) // 2
+    P = 2 * N + T + 1
+    hv = np.array(hv)
+    Kl = O.RBF_cov(d["x"][:, None], None, hv[1], hv[2])
+    Ks = O.RBF_cov(d["x"][:, None], None, hv[4], hv[5])
+    v = np.random.default_rng(3).standard_normal((4, P))
+    c = _lib.Context(0)
+    try:
+        c.set_data(d["x"], d["Y"])
+        Ltv = c.sep_prior_apply(hv, v, trans=True)
+        got = c.sep_prior_apply(hv, Ltv, trans=False)
+        c32 = float(np.float32(hv[8]))
+        want = np.concatenate([v[:, :N] @ Kl.T, v[:, N:2 * N] @ Ks.T, c32 * c32 * v[:, 2 * N:2 * N + T], v[:, -1:]], axis=1)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-11
+        assert np.array_equal(Ltv[:, 2 * N:2 * N + T], c32 * v[:, 2 * N:2 * N + T]) and np.array_equal(Ltv[:, -1], v[:, -1])
+        e = np.zeros((2, P))
+        e[0, 0] = 1.0
+        e[1, N] = 1.0
+        col = c.sep_prior_apply(hv, e, trans=False)
+        Ll, Ls = np.linalg.cholesky(Kl), np.linalg.cholesky(Ks)
+        assert np.allclose(col[0, :N], Ll[:, 0], rtol=1e-10, atol=1e-13) and np.all(col[0, N:] == 0)
+        assert np.allclose(col[1, N:2 * N], Ls[:, 0], rtol=1e-10, atol=1e-13) and np.all(col[1, :N] == 0) and np.all(col[1, 2 * N:] == 0)
+    finally:
+        c.close()
+
+
 def _metric_pieces(c, hv, P, B, r, seed):
     rng = np.random.default_rng(seed)
     Q, _ = np.linalg.qr(rng.standard_normal((P, r)))
