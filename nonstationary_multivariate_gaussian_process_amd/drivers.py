@@ -1034,3 +1034,125 @@ class BatchedHMCSeparable(LockStepHMC):
             energy_err[it] = np.where(np.isfinite(dH), dH, np.nan)
             samples[it] = self.q
         return samples, {"accept_rate": accepted / sample_size, "energy_error": energy_err}
+
+
+# ---- the whole recipe behind one call ---------------------------------------------------------------------------------------------
+def _sample_recipe(polish, build_metric, make_sampler, pars0, chains, iters, warm, warm_step, windows, window_iters, step_size,
+                   step_candidates, target_accept, progress, segment):
+    """Mode -> metric -> thermalising iterations -> (metric rebuilt at the chains' mean) x windows -> step search -> main run.
+    polish(pars0) -> (mode, NegLog, |grad|, evaluations); build_metric(point, k) -> metric; make_sampler(positions, metric, eps, seed)
+    -> an object with run(n) -> (samples [n, B, P], info).  Returns (samples [iters, B, P], info)."""
+    import time
+    say = progress if progress is not None else (lambda msg: None)
+    info = {}
+    t0 = time.time()
+    mode, nl, gn, nev = polish(np.asarray(pars0, dtype=np.float64).reshape(-1))
+    info["mode"] = {"pars": mode, "log_posterior": -nl, "whitened_gradient_norm": gn, "gradient_evaluations": nev, "seconds": time.time() - t0}
+    say("mode: log posterior %.4f, whitened |grad| %.3g, %d evaluations, %.1f s" % (-nl, gn, nev, time.time() - t0))
+    t0 = time.time()
+    metric = build_metric(mode, 0)
+    info["metric_at_the_mode"] = dict({k: v for k, v in metric.info.items() if k != "eigenvalues"}, rank=metric.rank, seconds=time.time() - t0)
+    say("metric at the mode: rank %d, lam max %.3g, most negative %.3g, %.1f s" % (
+        metric.rank, metric.info["lam_max"], metric.info["most_negative"], time.time() - t0))
+    cur = np.repeat(mode[None], chains, 0)
+    stages = []
+
+    def stage(eps, n, seed, tag):
+        hm = make_sampler(cur, metric, eps, seed)
+        t1 = time.time()
+        chunks, ees, acc, done = [], [], np.zeros(chains), 0
+        while done < n:
+            k = min(segment, n - done)
+            s_, inf = hm.run(k)
+            chunks.append(s_)
+            ees.append(inf["energy_error"])
+            acc += inf["accept_rate"] * k
+            done += k
+            if n > segment:
+                say("  %s: %d / %d iterations, %.1f s, accept so far %.3f" % (tag, done, n, time.time() - t1, acc.sum() / (done * chains)))
+        dt = time.time() - t1
+        ee = np.concatenate(ees)
+        st = {"stage": tag, "step_size": eps, "iterations": n, "seconds": dt, "accept_rate_mean": float(acc.sum() / (n * chains)),
+              "accept_rate_by_chain": (acc / n).tolist(), "median_abs_dH": float(np.nanmedian(np.abs(ee))),
+              "samples_per_s": n * chains / dt}
+        stages.append(st)
+        say("%s: %d iterations at eps %.3g in %.1f s, accept %.3f, median |dH| %.3g" % (tag, n, eps, dt, st["accept_rate_mean"], st["median_abs_dH"]))
+        return np.concatenate(chunks), ee
+
+    s = None
+    if warm > 0:
+        # all chains start AT the mode, where the first trajectories convert P / 2 units of kinetic into potential energy: the leapfrog
+        # error of that transfer rejects every step worth having, so a few iterations at a small step come first
+        s, _ = stage(warm_step, warm, 300, "warm-up")
+        cur = s[-1]
+    for wdw in range(int(windows)):
+        center = (s[-max(10, s.shape[0] // 2):].mean((0, 1)) if s is not None else mode)
+        t0 = time.time()
+        metric = build_metric(center, 1 + wdw)
+        say("window %d: metric at the chains' mean: rank %d, lam max %.3g, most negative %.3g, %.1f s" % (
+            wdw, metric.rank, metric.info["lam_max"], metric.info["most_negative"], time.time() - t0))
+        s, _ = stage(min(step_candidates), window_iters, 400 + wdw, "adaptation window %d" % wdw)
+        cur = s[-1]
+    if step_size == "auto":
+        tried, best = [], None
+        for eps in step_candidates:
+            _, inf = make_sampler(cur, metric, eps, 200).run(6)
+            a_ = float(inf["accept_rate"].mean())
+            tried.append({"step_size": eps, "accept_rate_mean": a_, "median_abs_dH": float(np.nanmedian(np.abs(inf["energy_error"])))})
+            say("step search: eps %.3g accept %.2f median |dH| %.3g" % (eps, a_, tried[-1]["median_abs_dH"]))
+            if a_ >= target_accept:
+                best = eps
+            elif best is not None:
+                break
+        eps = best if best is not None else min(step_candidates)
+        info["step_search"] = tried
+    else:
+        eps = float(step_size)
+    S, ee = stage(eps, iters, 1, "main")
+    info.update(step_size=eps, stages=stages, metric=metric, energy_error=ee, accept_rate=np.array(stages[-1]["accept_rate_by_chain"]))
+    return S, info
+
+
+def sample_nonseparable(x, Y, hyper_pars, pars0, chains=8, iters=1000, num_steps_in_leap=20, rank=64, polish=300, warm=40,
+                        warm_step=0.03, windows=0, window_iters=50, step_size="auto", step_candidates=(0.05, 0.065, 0.08, 0.1, 0.12),
+                        target_accept=0.7, step_jitter=0.2, seed=1, ctx=None, progress=None, segment=50):
+    """The sampler call of ``Nonseparable_model.py:228-231`` for ``chains`` chains in lock-step, as the recipe under which it
+    converges at N = 2048 (``tools/hmc_1000.py`` is the same recipe with its diagnostics): mode by metric-preconditioned
+    L-BFGS from ``pars0`` (:func:`polish_map`), :class:`PriorMetric` there (:func:`prior_lowrank_metric`), ``warm`` thermalising
+    iterations at ``warm_step``, optionally ``windows`` re-adaptations of the metric at the chains' mean, a step search for
+    ``target_accept``, then ``iters`` iterations of :class:`BatchedHMC` with ``step_jitter``.  ``progress``: a callable for one-line
+    messages.  Returns (samples [iters, chains, P], info: mode, metrics, stages, step_size, energy_error, accept_rate)."""
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+
+    def make_sampler(pos, metric, eps, sd):
+        return BatchedHMC(x, Y, hyper_pars, pos, step_size=eps, num_steps_in_leap=num_steps_in_leap, seed=sd + 1000 * seed, ctx=ctx, M=metric,
+                          step_jitter=step_jitter)
+    return _sample_recipe(lambda p: polish_map(x, Y, hyper_pars, p, maxiter=polish, rounds=8, rank=rank, probes=rank + 32, ctx=ctx,
+                                               verbose=progress),
+                          lambda q, k: prior_lowrank_metric(x, Y, hyper_pars, q, rank=rank, oversample=32, seed=7 + k, ctx=ctx,
+                                                            batch=min(rank + 32, 128)),
+                          make_sampler, pars0, chains, iters, warm, warm_step, windows, window_iters, step_size, step_candidates,
+                          target_accept, progress, segment)
+
+
+def sample_separable(x, Y, hyper_pars, pars0, chains=8, iters=1000, num_steps_in_leap=20, rank=64, polish=400, warm=50, warm_step=0.04,
+                     windows=2, window_iters=50, step_size="auto", step_candidates=(0.08, 0.11, 0.15), target_accept=0.8,
+                     step_jitter=0.2, seed=1, ctx=None, progress=None, segment=25, batch=16):
+    """The same for the separable model (``Separable_model.py:209-210``; :class:`SeparablePriorMetric`, :class:`BatchedHMCSeparable`).
+    ``windows`` defaults to 2: this posterior's mass sits far from its mode (the sigma(x) <-> B scale ridge), so the metric is
+    rebuilt at the chains' mean after the warm-up (``tools/hmc_sep.py``)."""
+    from . import _lib
+    ctx = ctx if ctx is not None else _lib.default_context()
+    x, Y = np.asarray(x, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+
+    def make_sampler(pos, metric, eps, sd):
+        return BatchedHMCSeparable(x, Y, hyper_pars, pos, step_size=eps, num_steps_in_leap=num_steps_in_leap, seed=sd + 1000 * seed, ctx=ctx,
+                                   M=metric, step_jitter=step_jitter)
+    return _sample_recipe(lambda p: polish_map_separable(x, Y, hyper_pars, p, maxiter=polish, rounds=8, rank=rank, probes=rank + 32,
+                                                         batch=batch, ctx=ctx, verbose=progress),
+                          lambda q, k: separable_prior_metric(x, Y, hyper_pars, q, rank=rank, oversample=32, seed=3 + k, ctx=ctx,
+                                                              batch=batch),
+                          make_sampler, pars0, chains, iters, warm, warm_step, windows, window_iters, step_size, step_candidates,
+                          target_accept, progress, segment)

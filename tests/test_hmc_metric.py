@@ -478,3 +478,31 @@ def test_separable_sampler_under_its_prior_metric_mixes_and_agrees_with_the_dens
     assert a[:, :, 2 * N].mean() - q0[2 * N] > 3.0 * a[:, :, 2 * N].std()
     si, ii = BatchedHMCSeparable(d["x"], d["Y"], h, init, step_size=2e-4, num_steps_in_leap=L, seed=40).run(400)
     assert np.nanmedian(H.split_rhat(si[200:])) > 1.5
+
+
+@pytest.mark.gpu
+def test_one_call_recipes_converge_on_both_models():
+    """drivers.sample_nonseparable / sample_separable: the whole recipe (mode, metric, warm-up, adaptation windows, step search, main
+    run) behind one call, from the start point a script would hand over -- split R-hat of the second half near 1 on every parameter."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hmc_1000 as H
+    from nonstationary_multivariate_gaussian_process_amd import sim
+    from nonstationary_multivariate_gaussian_process_amd.drivers import sample_nonseparable, sample_separable
+    N, M = 64, 3
+    log = []
+    d = sim.simulate_nonseparable(N, M, seed=5)
+    S, info = sample_nonseparable(d["x"], d["Y"], sim.HYPER_SVC, sim.perturb(d["pars_true"], 0.05, 0.7), chains=8, iters=600,
+                                  num_steps_in_leap=10, rank=32, windows=1, window_iters=100, step_candidates=(0.08, 0.12, 0.16),
+                                  progress=log.append)
+    assert S.shape == (600, 8, N * 7 + 1) and info["stages"][-1]["stage"] == "main" and info["stages"][-1]["accept_rate_mean"] > 0.65
+    assert info["mode"]["whitened_gradient_norm"] < 1.0 and info["metric"].rank >= 8 and any("step search" in m for m in log)
+    rh = H.split_rhat(S[300:])
+    assert np.nanmedian(rh) < 1.05 and np.nanquantile(rh, 0.99) < 1.3, (np.nanmedian(rh), np.nanquantile(rh, 0.99), np.nanmax(rh))
+    ds = sim.simulate_separable(N, M, 4)
+    S2, info2 = sample_separable(ds["x"], ds["Y"], sim.HYPER_SEP, sim.perturb(ds["pars_true"], 0.05, 0.4), chains=8, iters=600,
+                                 num_steps_in_leap=10, rank=32, warm=200, windows=2, window_iters=300, batch=8)
+    assert S2.shape == (600, 8, 2 * N + 7) and info2["stages"][-1]["accept_rate_mean"] > 0.7
+    assert [st["stage"] for st in info2["stages"]][:3] == ["warm-up", "adaptation window 0", "adaptation window 1"]
+    rh2 = H.split_rhat(S2[300:])
+    assert np.nanmedian(rh2) < 1.06 and np.nanquantile(rh2, 0.99) < 1.3, (np.nanmedian(rh2), np.nanquantile(rh2, 0.99), np.nanmax(rh2))

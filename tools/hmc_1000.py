@@ -13,6 +13,8 @@ plus a rank-`--rank` correction for the likelihood's curvature found by randomis
 M = diag(1 / var) (round 4: does not mix).  The step size is chosen by a short search for ~0.8 acceptance (`--step auto`; the
 reference's 1e-4 is rejected every time at this size under the identity: profiles/r03_hmc_steps.txt).
 
+(`drivers.sample_nonseparable` packages the same recipe -- mode, metric, warm-up, step search, run -- behind one call; this tool keeps
+its own spelling because it also runs the round-4 comparisons `--mass diag|identity` and writes the diagnostics.)
 Writes one JSON document: acceptance, quantiles of |dH|, samples/s and gradient evaluations/s of the main run, the MULTI-CHAIN
 effective sample size (rank-normalised split chains, between-chain variance in the denominator: Vehtari et al. 2021 -- chains that
 have not mixed get a small ESS, unlike a sum of per-chain figures), ESS per second, and split-R-hat per parameter block (l~(x), the T columns of uL(x), log sigma^2), the posterior mean of l~(x) against the generating curve and the MAP estimate,
