@@ -1,5 +1,7 @@
 """MAP / HMC drivers.  CPU part: the HMC machinery on an analytic Gaussian target;
 GPU part: the reference's MAP trajectory fixture and HMC energy conservation on the real potential."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -214,6 +216,19 @@ def test_the_scripts_sampler_line_runs_unchanged_on_the_shipped_hmc_sampler():
                                                duplicate_samples=True, TensorType=settings.torchType, **hyper_pars)
         s2, info2 = hmc2.main_hmc_loop()
         assert s2.shape == (3, P) and info2["step_size"] > 0
+        # opt-in for the UNCHANGED script: NMGP_HMC_RECIPE=1 turns the same call into the recipe under which the chains converge
+        # (mode from init_position, prior-factor metric, warm-up, step search, NMGP_HMC_CHAINS chains on the GPU); same return shape
+        os.environ["NMGP_HMC_RECIPE"], os.environ["NMGP_HMC_CHAINS"] = "1", "4"
+        try:
+            hmc3 = HMC_Sampler.HMC_sampler.sampler(sample_size=40, potential_func=logpos.nlogpos_obj_SVC, init_position=estPars,
+                                                   step_size=1e-4, num_steps_in_leap=10, x=x, Y=Y, duplicate_samples=True,
+                                                   TensorType=settings.torchType, **hyper_pars)
+            s3, info3 = hmc3.main_hmc_loop()
+        finally:
+            del os.environ["NMGP_HMC_RECIPE"], os.environ["NMGP_HMC_CHAINS"]
+        assert s3.shape == (40, P) and info3["all_chains"].shape == (40, 4, P) and np.array_equal(s3, info3["all_chains"][:, 0])
+        assert info3["accept_rate"] > 0.5 and info3["step_size"] >= 0.05 and info3["recipe"]["metric"].rank >= 4
+        assert np.sqrt(np.mean((s3[-1] - estPars) ** 2)) > 20 * np.sqrt(np.mean((sample[-1] - estPars) ** 2))      # it goes places
     finally:
         for k, v in saved.items():
             if v is None:
