@@ -123,6 +123,11 @@ def test_parity_suite_passes_with_nan_poisoned_device_buffers():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu",
                           "-x", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:]
+    # ... and the sampler's metric kernels (round 5): coordinate changes, trajectories against the dense-mass path, batched = single
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hmc_metric.py"), "-q", "-m", "gpu", "-x",
+                          "-p", "no:cacheprovider", "-k", "prior_apply or trajectories or bits or multi_subject"],
+                         capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("env_extra", [
