@@ -4,8 +4,9 @@
 // assembly, the trace / weighted-sum pass over the M blocks of -S_p^-1 and the per-location adjoint are one launch each for the
 // whole batch instead of 5 + 7 launches per chain:
 //   k_sep_prep_b     ell = exp(tilde_l), sig = exp(tilde_sigma), yt_p = (V_B^T kron I) y        -- all chains
-//   k_sep_blocks_b   S_bp = wB_b[p] K_x,b + sigma2_b I written STRAIGHT from (x, ell_b, sig_b): K_x,b itself is stored only when the
-//                    gradient needs it (value path: M N^2/2 doubles per chain instead of (2M + 1) N^2/2 written + M N^2/2 read)
+//   k_sep_blocks_b4  S_bp = wB_b[p] K_x,b + sigma2_b I written STRAIGHT from (x, ell_b, sig_b): K_x,b itself is stored only when the
+//   (k_sep_blocks_b) gradient needs it (value path: M N^2/2 doubles per chain instead of (2M + 1) N^2/2 written + M N^2/2 read);
+//                    tiles dealt to the XCDs column by column, so that each L2 hands HBM long runs of a column
 //   k_sep_reduce_b   ONE pass over the M blocks -S_bp^-1: tr S_p^-1, <S_p^-1, K_x>, |alpha_p|^2 and C_b = sum_p wB[p] S_p^-1
 //                    (each block is read once; round 4 read the five blocks twice, in two kernels per chain)
 //   k_sep_adjoint_b  the fused per-location adjoint of nmgp_kernels_eig.hip with the chain as blockIdx.z
@@ -64,10 +65,27 @@ template <int M>
 __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__ x, const double* __restrict__ ell,
                                                        const double* __restrict__ sig, const double* __restrict__ small,
                                                        int small_per, int N, double* __restrict__ S, int ldo, long long bstride,
-                                                       double* __restrict__ Kout) {
+                                                       double* __restrict__ Kout, int remap) {
     constexpr int TJ = 64;
     __shared__ double sx[TJ], sl[TJ], ss[TJ];
-    const int I = blockIdx.x, J = blockIdx.y, b = blockIdx.z;
+    int I = blockIdx.x, J = blockIdx.y;
+    const int b = blockIdx.z;
+    if (remap) {
+        // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup g of the launch
+        // takes tile t = (g mod 8) * per + g / 8 of the lower-triangular tile list, enumerated column by column (J, then I = J ..):
+        // the tiles ONE XCD works on at a time are vertical neighbours -- the adjacent 512-byte segments of the same 64 columns --
+        // and its L2 hands HBM runs of several KB per column instead of eight L2s handing over 512 bytes each.
+        const int NI = (N + 63) / 64, ntl = NI * (NI + 1) / 2, per = (ntl + 7) / 8;
+        const int g = blockIdx.x, t = (g & 7) * per + (g >> 3);
+        if ((g >> 3) >= per || t >= ntl) return;
+        int rem = t;
+        J = 0;
+        while (rem >= NI - J) {
+            rem -= NI - J;
+            ++J;
+        }
+        I = J + rem;
+    }
     if (I < J) return;
     const double* eb = ell + (size_t)b * N;
     const double* sb = sig + (size_t)b * N;
@@ -129,11 +147,113 @@ __global__ __launch_bounds__(256) void k_sep_blocks_b(const double* __restrict__
     }
 }
 
+// The same blocks from 128 x 32 location tiles (the default; NMGP_SEP_BLOCKS=4): a lane owns the row pair (i, i + 1), so every store instruction
+// of a wave writes ONE KILOBYTE of a column (16 bytes per lane), in the XCD-aware tile order of the remapped kernel above (a column
+// of tiles per XCD at a time: its L2 hands HBM runs of many KB).  A wave takes 8 of the tile's 32 columns.  Even N only (16-byte
+// alignment of K_x's columns); the launcher falls back to the 64 x 64 kernel otherwise.  Row pairs that straddle the diagonal are
+// written whole (the element above the diagonal is scratch to every consumer: DESIGN section 2).
+template <int M>
+__global__ __launch_bounds__(256) void k_sep_blocks_b4(const double* __restrict__ x, const double* __restrict__ ell,
+                                                        const double* __restrict__ sig, const double* __restrict__ small,
+                                                        int small_per, int N, double* __restrict__ S, int ldo, long long bstride,
+                                                        double* __restrict__ Kout) {
+    constexpr int TJ = 32, TI = 128;
+    __shared__ double sx[TJ], sl[TJ], ss[TJ];
+    const int b = blockIdx.z;
+    const int NI = (N + TI - 1) / TI, NJ = (N + TJ - 1) / TJ;
+    // lower-triangular tile list, column by column: column J holds the row tiles I = J / 4 .. NI - 1
+    int ntl = 0;
+    for (int J = 0; J < NJ; ++J) ntl += NI - J / 4;
+    const int per = (ntl + 7) / 8;
+    const int g = blockIdx.x, t = (g & 7) * per + (g >> 3);
+    if ((g >> 3) >= per || t >= ntl) return;
+    int rem = t, J = 0;
+    while (rem >= NI - J / 4) {
+        rem -= NI - J / 4;
+        ++J;
+    }
+    const int I = J / 4 + rem;
+    const double* eb = ell + (size_t)b * N;
+    const double* sb = sig + (size_t)b * N;
+    const double* sm = small + (size_t)b * small_per;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j0 = J * TJ;
+    if (tid < TJ) {
+        const int j = j0 + tid;
+        sx[tid] = (j < N) ? x[j] : 0.0;
+        sl[tid] = (j < N) ? eb[j] : 1.0;
+        ss[tid] = (j < N) ? sb[j] : 1.0;
+    }
+    __syncthreads();
+    const int i = I * TI + 2 * lane;                   // rows i, i + 1 (N even: both valid or both out)
+    if (i >= N) return;
+    double wB[M];
+#pragma unroll
+    for (int p = 0; p < M; ++p) wB[p] = sm[p];
+    const double sigma2 = sm[M + M * M];
+    const double xa = x[i], la = eb[i], sa = sb[i], xb = x[i + 1], lb = eb[i + 1], sbb = sb[i + 1];
+    const double xa2 = xa * xa, la2 = la * la, xb2 = xb * xb, lb2 = lb * lb;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    union D4 {
+        double d[2];
+        v4i_t v;
+    };
+    double* Sb = S + (size_t)b * M * bstride;
+    __amdgpu_buffer_rsrc_t rs[M];
+#pragma unroll
+    for (int p = 0; p < M; ++p) rs[p] = __builtin_amdgcn_make_buffer_rsrc((void*)(Sb + (size_t)p * bstride), 0, 0x7fffffff, 0x00020000);
+    const bool wantK = Kout != nullptr;
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(wantK ? Kout + (size_t)b * N * N : Sb), 0, 0x7fffffff, 0x00020000);
+    for (int jj = 0; jj < TJ / 4; ++jj) {
+        const int k = w * (TJ / 4) + jj;
+        const int j = j0 + k;
+        if (j >= N) break;
+        if (i + 1 < j) continue;                       // the whole pair lies above the diagonal
+        const double xj = sx[k], lj = sl[k], sj = ss[k], xj2 = xj * xj, lj2 = lj * lj;
+        const double da = (xa2 + xj2) - 2.0 * (xa * xj), Aa = la2 + lj2;
+        const double db = (xb2 + xj2) - 2.0 * (xb * xj), Ab = lb2 + lj2;
+        double va = (sa * sj) * sqrt(2.0 * (la * lj) / Aa) * exp(-da / Aa);       // kernels.py:69-72
+        double vb = (sbb * sj) * sqrt(2.0 * (lb * lj) / Ab) * exp(-db / Ab);
+        if (i == j) va = NMGP_JITTER + va;
+        if (i + 1 == j) vb = NMGP_JITTER + vb;
+        D4 u;
+        if (wantK) {
+            u.d[0] = va;
+            u.d[1] = vb;
+            __builtin_amdgcn_raw_buffer_store_b128(u.v, rk, (j * N + i) * 8, 0, 0);
+        }
+        const int off = (j * ldo + i) * 8;
+        const double ga = (i == j) ? sigma2 : 0.0, gb = (i + 1 == j) ? sigma2 : 0.0;
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+            u.d[0] = wB[p] * va + ga;
+            u.d[1] = wB[p] * vb + gb;
+            __builtin_amdgcn_raw_buffer_store_b128(u.v, rs[p], off, 0, 0);
+        }
+    }
+}
+
 template <int M>
 static void launch_sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per,
                                 int N, double* S, int ldo, long long bstride, double* Kout, int B) {
-    NMGP_LAUNCH((k_sep_blocks_b<M>), dim3(cdiv_s(N, 64), cdiv_s(N, 64), B), dim3(256), 0, s, x, ell, sig, small, small_per, N, S, ldo,
-                bstride, Kout);
+    // NMGP_SEP_BLOCKS: 4 (default) 128 x 32 tiles, 1 KB stores, XCD-aware order; 3: 64 x 64 tiles in the XCD-aware order (also the
+    // fallback for odd N); 1: 64 x 64 tiles in grid order (round 5's first form, kept for the A/B: 2.43 / 1.69 / 1.49 ms for 16 chains
+    // of N = 4096, D = 5 -- 1 / 3 / 4)
+    static const int variant = [] { const char* e = std::getenv("NMGP_SEP_BLOCKS"); return e ? std::atoi(e) : 4; }();
+    if (variant == 4 && (N & 1) == 0) {
+        const int NI = cdiv_s(N, 128), NJ = cdiv_s(N, 32);
+        int ntl = 0;
+        for (int J = 0; J < NJ; ++J) ntl += NI - J / 4;
+        NMGP_LAUNCH((k_sep_blocks_b4<M>), dim3(8 * ((ntl + 7) / 8), 1, B), dim3(256), 0, s, x, ell, sig, small, small_per, N, S, ldo, bstride,
+                    Kout);
+    } else if (variant == 3 || variant == 4) {
+        const int NI = cdiv_s(N, 64), ntl = NI * (NI + 1) / 2, per = (ntl + 7) / 8;
+        NMGP_LAUNCH((k_sep_blocks_b<M>), dim3(8 * per, 1, B), dim3(256), 0, s, x, ell, sig, small, small_per, N, S, ldo, bstride, Kout, 1);
+    } else {
+        NMGP_LAUNCH((k_sep_blocks_b<M>), dim3(cdiv_s(N, 64), cdiv_s(N, 64), B), dim3(256), 0, s, x, ell, sig, small, small_per, N, S, ldo,
+                    bstride, Kout, 0);
+    }
 }
 
 void sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per, int N, int M,

@@ -130,6 +130,19 @@ def test_parity_suite_passes_with_nan_poisoned_device_buffers():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("variant", ["1", "3"])
+def test_separable_batch_under_the_selectable_block_assembly_kernels(variant):
+    """NMGP_SEP_BLOCKS: the batched separable evaluation's block-assembly kernel in its other forms (64 x 64 tiles in grid order /
+    in the XCD-aware order; the default is 128 x 32 tiles with 16-byte stores) against the same goldens and single-chain evaluations."""
+    env = dict(os.environ)
+    env["NMGP_SEP_BLOCKS"] = variant
+    env["NMGP_ROUND"] = "variants"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                          "-p", "no:cacheprovider", "-k", "separable_chains_batched"], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("env_extra", [
     {"NMGP_SYRK_SMALL_MAX": "100000", "NMGP_CHOL_NB1": "128"},      # every K >= 128 update on 64x64 tiles, look-ahead from n > 256
     {"NMGP_SYRK_SMALL_MAX": "100000", "NMGP_CHOL_NB1": "192", "NMGP_CHOL_PANEL": "rl"},   # panels that are no multiple of 128
