@@ -27,6 +27,9 @@ shows them (value_grad_evals_per_s, hmc_samples_per_s, roofline_frac_end_to_end,
   grad          -- the MCMC-relevant rate: value+gradient evaluations / second at the same chain count (HMC spends 20
                    leapfrog GRADIENT evaluations per sample, Nonseparable_model.py:228-231), with its own ms_per_step and
                    its end-to-end roofline on n^3 flop per evaluation (W_fb = n^3).
+  hmc           -- (single-GPU lines) BatchedHMC at the same chain count: 5 samples of 20 leapfrog steps under the prior-factor metric
+                   (drivers.PriorMetric; --hmc-mass identity,... for the others) from committed typical-set positions: samples/s,
+                   gradient evaluations/s, acceptance, and where a sample's wall time goes (device_share).
   cpu_baseline  -- the NumPy/SciPy oracle (oracle/nmgp_oracle.py) timed on this host's cores on a bounded sample of the
                    same workload by rank 0 AFTER the timed region (the other ranks wait at the final barrier; fewer evaluations
                    when N > 1): Cholesky formulation, and the reference's own inverse+logdet formulation (logpos.py:352-353)
