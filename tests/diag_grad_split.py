@@ -1,4 +1,4 @@
-"""Where the gradient's distance to the CPU oracle comes from: likelihood part vs GP-prior part (python tools/grad_split.py on the GPU box)."""
+"""Where the gradient's distance to the CPU oracle comes from: likelihood part vs GP-prior part (python tests/diag_grad_split.py on the GPU box; lives under tests/ because it uses the CPU oracle as the checker)."""
 import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from nonstationary_multivariate_gaussian_process_amd import _lib, sim
