@@ -821,7 +821,8 @@ def run_separable(a, rank, world, be):
                     "grad_norm_chain0": float(np.linalg.norm(ev.grads[0])) if ev.grads is not None else None,
                     "roofline": {"what": "end to end: D N^3 flop per value+gradient evaluation x evals/s per GPU", "bound": "mfma",
                                  "achieved": g_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g_tf / FP64_MATRIX_PEAK_TFLOPS,
-                                 "traffic": None, "traffic_note": "no committed PMC measurement for this workload"},
+                                 "traffic": (measured_traffic(N, M, B, True, "separable") if prof is not None else (None, "no HIP backend", None))[0],
+                                 "traffic_note": (measured_traffic(N, M, B, True, "separable") if prof is not None else (None, "no HIP backend", None))[1]},
                     "stage_ms": {k: (v[0] / max(v[1], 1)) for k, v in g_stage.items() if v[1] > 0}}
     ids = [rank * B + b for b in range(B)]
     stats, table = chains.reduce_rows(unit_rows(ids, a.steps, out, status), B * world, world, device=be.device)
@@ -831,8 +832,11 @@ def run_separable(a, rank, world, be):
         per_eval = M * float(N) ** 3 / (1.0 if want_grad else 3.0)
         e2e = value * per_eval / 1e12 / world / FP64_MATRIX_PEAK_TFLOPS
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in stage.items() if v[1] > 0}
+        traffic, traffic_note, traffic_scope = measured_traffic(N, M, B, want_grad, "separable") if prof is not None else (
+            None, "no HIP backend", None)
         rl = {"kernel": "k_syrk_lower", "bound": "mfma", "achieved": 0.0, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 0.0,
-              "traffic": None, "traffic_note": "no committed PMC measurement for this workload"}
+              "traffic": traffic, "traffic_note": traffic_note, "traffic_scope": traffic_scope,
+              "algorithmic_bytes_per_step": B * M * 8.0 * N * (N + 1) / 2.0 * 2.0}        # the blocks written once, the factors read back once
         if kprof is not None:
             syrk_ms, syrk_cnt, syrk_flop, syrk_bytes = kprof["syrk"]
             ach = syrk_flop / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
