@@ -578,7 +578,7 @@ namespace {
 
 struct SepBatchLayout {
     size_t o_P, o_ell, o_sig, o_K, o_small, o_yt, o_z, o_alpha, o_red, o_info, o_R, o_R2, o_q, o_S;
-    size_t o_Cneg = 0, o_part = 0, o_C = 0, o_W = 0, o_Xi = 0, o_g = 0, o_tr = 0;
+    size_t o_Cneg = 0, o_part = 0, o_C = 0, o_Xi = 0, o_g = 0, o_tr = 0;
     size_t total = 0, small_per = 0, tri_part = 0;
     int ld = 0;
     long long bs = 0;
@@ -604,8 +604,7 @@ SepBatchLayout sep_batch_layout(int B, int N, int M, int T, bool want_grad) {
         L.o_Cneg = take(BM * NN);
         L.o_part = take(std::max(BM * L.tri_part, (size_t)B * NJ * N * 2 + 8));
         L.o_C = take((size_t)B * NN);
-        L.o_W = take((size_t)B * N * M);
-        L.o_Xi = take((size_t)B * M * M);
+        L.o_Xi = take((size_t)B * NMGP_SEP_TR_G * M * (M + 1) / 2);      // partial quadratic forms alpha_p^T K alpha_q, per chain and group
         L.o_g = take((size_t)B * 2 * N);
         L.o_tr = take(BM * NMGP_SEP_TR_G * 3);
     }
@@ -705,9 +704,8 @@ int sep_batch_core(nmgp_ctx* c, const double* pars, int B, const double hyper[9]
     // epilogue discards) ----
     std::vector<double> hx, hg, hR2, htr;
     if (want_grad) {
-        double *Cneg = slab + L.o_Cneg, *part = slab + L.o_part, *C = slab + L.o_C, *W = slab + L.o_W, *Xi = slab + L.o_Xi, *d_g = slab + L.o_g;
+        double *Cneg = slab + L.o_Cneg, *part = slab + L.o_part, *C = slab + L.o_C, *Xi = slab + L.o_Xi, *d_g = slab + L.o_g;
         double* trs = slab + L.o_tr;
-        const double one = 1.0, zero = 0.0;
         {
             NmgpStage sp(c, NMGP_STAGE_INVERSE);
             tri_gemv_upper(s, S + xoff, ld, N, z, alpha, part, BM, bs, (long long)L.tri_part);
@@ -715,20 +713,12 @@ int sep_batch_core(nmgp_ctx* c, const double* pars, int B, const double hyper[9]
         }
         {
             NmgpStage sp(c, NMGP_STAGE_ADJOINT);
-            sep_reduce_b(s, Cneg, dK, alpha, d_small, sp_, N, M, G, C, trs, B);
+            // traces, <S^-1, K>, the weighted sum C and the M x M quadratic forms alpha_p^T K alpha_q: ONE pass over -S^-1 and K_x
+            sep_reduce_b(s, Cneg, dK, alpha, d_small, sp_, N, M, G, C, trs, Xi, B);
             fill_lower_to_full(s, C, N, N, B);
             sep_adjoint_b(s, c->d_x, d_ell, d_sig, alpha, d_small, sp_, M, C, N, part, d_g, B);
-            // Xi_b = alpha_b^T (K_b alpha_b): the M x M quadratic forms, strided-batched over the chains (W zeroed so that a
-            // beta = 0 implemented as a scaling cannot carry stale NaNs over)
-            HIP_TRY(c, hipMemsetAsync(W, 0, (size_t)B * N * M * sizeof(double), s));
-            BLAS_TRY(c, rocblas_dsymm_strided_batched(c->blas, rocblas_side_left, rocblas_fill_lower, N, M, &one, dK, N, (rocblas_stride)NN,
-                                                      alpha, N, (rocblas_stride)((size_t)M * N), &zero, W, N,
-                                                      (rocblas_stride)((size_t)M * N), B));
-            BLAS_TRY(c, rocblas_dgemm_strided_batched(c->blas, rocblas_operation_transpose, rocblas_operation_none, M, M, N, &one, alpha, N,
-                                                      (rocblas_stride)((size_t)M * N), W, N, (rocblas_stride)((size_t)M * N), &zero, Xi, M,
-                                                      (rocblas_stride)((size_t)M * M), B));
         }
-        hx.assign((size_t)B * M * M, 0.0);
+        hx.assign((size_t)B * G * M * (M + 1) / 2, 0.0);
         hg.assign((size_t)B * 2 * N, 0.0);
         hR2.assign((size_t)N * 2 * B, 0.0);
         htr.assign((size_t)BM * G * 3, 0.0);
@@ -770,10 +760,20 @@ int sep_batch_core(nmgp_ctx* c, const double* pars, int B, const double hyper[9]
                 aa[p] += tb[((size_t)p * G + g) * 3 + 2];
             }
         // d loglik / dB = V_B Xi V_B^T,  Xi[p,p'] = 1/2 (alpha_p^T K alpha_p' - d_pp' <S_p^-1, K>)
-        std::vector<double> Xs((size_t)M * M), dB((size_t)M * M, 0.0), g_uL;
-        const double* hxb = hx.data() + (size_t)b * M * M;
+        std::vector<double> Xs((size_t)M * M), dB((size_t)M * M, 0.0), g_uL, aKa((size_t)M * M, 0.0);
+        {
+            const int NX = M * (M + 1) / 2;
+            const double* hxb = hx.data() + (size_t)b * G * NX;
+            int e = 0;
+            for (int p = 0; p < M; ++p)
+                for (int q = p; q < M; ++q, ++e) {
+                    double acc = 0.0;
+                    for (int g = 0; g < G; ++g) acc += hxb[(size_t)g * NX + e];
+                    aKa[(size_t)p * M + q] = aKa[(size_t)q * M + p] = acc;
+                }
+        }
         for (int p = 0; p < M; ++p)
-            for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (hxb[(size_t)q * M + p] - (p == q ? tk[p] : 0.0));
+            for (int q = 0; q < M; ++q) Xs[(size_t)p * M + q] = 0.5 * (aKa[(size_t)q * M + p] - (p == q ? tk[p] : 0.0));
         for (int i = 0; i < M; ++i)
             for (int j = 0; j < M; ++j) {
                 double acc = 0.0;

@@ -388,7 +388,7 @@ void sep_prep_b(hipStream_t s, const double* pars, long long P, const double* Y,
 void sep_blocks_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* small, int small_per, int N, int M,
                   double* S, int ldo, long long bstride, double* Kout, int B);
 void sep_reduce_b(hipStream_t s, const double* Cneg, const double* K, const double* alpha, const double* small, int small_per, int N,
-                  int M, int G, double* C, double* out, int B);
+                  int M, int G, double* C, double* out, double* xi, int B);
 void sep_adjoint_b(hipStream_t s, const double* x, const double* ell, const double* sig, const double* U, const double* small,
                    int small_per, int M, const double* C, int N, double* part, double* g, int B);
 void two_col_rhs_b(hipStream_t s, const double* pars, long long P, double mu_a, double mu_b, int N, double* R, int B);

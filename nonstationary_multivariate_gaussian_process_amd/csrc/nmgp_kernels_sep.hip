@@ -7,8 +7,9 @@
 //   k_sep_blocks_b4  S_bp = wB_b[p] K_x,b + sigma2_b I written STRAIGHT from (x, ell_b, sig_b): K_x,b itself is stored only when the
 //   (k_sep_blocks_b) gradient needs it (value path: M N^2/2 doubles per chain instead of (2M + 1) N^2/2 written + M N^2/2 read);
 //                    tiles dealt to the XCDs column by column, so that each L2 hands HBM long runs of a column
-//   k_sep_reduce_b   ONE pass over the M blocks -S_bp^-1: tr S_p^-1, <S_p^-1, K_x>, |alpha_p|^2 and C_b = sum_p wB[p] S_p^-1
-//                    (each block is read once; round 4 read the five blocks twice, in two kernels per chain)
+//   k_sep_reduce_b   ONE pass over the M blocks -S_bp^-1 and K_x: tr S_p^-1, <S_p^-1, K_x>, |alpha_p|^2, C_b = sum_p wB[p] S_p^-1 and
+//                    the M x M quadratic forms alpha_p^T K_x alpha_q (each block is read once; round 4 read the five blocks
+//                    twice, in two kernels per chain, and K_x once more in a library dsymm)
 //   k_sep_adjoint_b  the fused per-location adjoint of nmgp_kernels_eig.hip with the chain as blockIdx.z
 // Arithmetic per element is the single-chain kernels' (k_cov_sym<GIBBS>, k_sep_blocks, k_sep_adjoint): same expressions, same order.
 #include "nmgp_internal.h"
@@ -270,62 +271,80 @@ void sep_blocks_b(hipStream_t s, const double* x, const double* ell, const doubl
     }
 }
 
-// ONE pass over the M blocks Cneg_bp = -S_bp^-1 (lower, ld = N) of chain b = blockIdx.y; workgroup g = blockIdx.x takes the columns
-// j = g, g + G, ...:   out[((b M + p) G + g) 3 + {0, 1, 2}] = partial tr S_p^-1, <S_p^-1, K> (full symmetric inner product from the
-// lower triangles), |alpha_p|^2 (g = 0 only) -- the host adds the G partials in a fixed order --, and
-// C_b[i, j] = sum_p wB[p] S_p^-1[i, j] on the lower triangle.
+// ONE pass over the M blocks Cneg_bp = -S_bp^-1 (lower, ld = N) of chain b = blockIdx.y AND over K_x,b; workgroup g = blockIdx.x takes
+// the columns j = g, g + G, ...:
+//   out[((b M + p) G + g) 3 + {0, 1, 2}] = partial tr S_p^-1, <S_p^-1, K> (full symmetric inner product from the lower triangles),
+//                                          |alpha_p|^2 (g = 0 only)
+//   xi[(b G + g) M(M+1)/2 + idx(p, q)]   = partial alpha_p^T K alpha_q for p <= q (idx row-major over the upper triangle): the M x M
+//                                          quadratic forms of d loglik / dB, which round 5's first form left to a library dsymm + dgemm
+//                                          per chain (2.9 ms of a 16-chain gradient step, 256 small launches)
+//   C_b[i, j] = sum_p wB[p] S_p^-1[i, j] on the lower triangle.
+// The host adds the G partials in a fixed order.
+template <int M>
 __global__ __launch_bounds__(256) void k_sep_reduce_b(const double* __restrict__ Cneg, const double* __restrict__ K,
                                                        const double* __restrict__ alpha, const double* __restrict__ small,
-                                                       int small_per, int N, int M, int G, double* __restrict__ C,
-                                                       double* __restrict__ out) {
+                                                       int small_per, int N, int G, double* __restrict__ C,
+                                                       double* __restrict__ out, double* __restrict__ xi) {
+    constexpr int NX = M * (M + 1) / 2;
     __shared__ double sh[16];
-    __shared__ double swB[NMGP_MAX_OUTPUTS];
     const int g = blockIdx.x, b = blockIdx.y;
     const size_t NN = (size_t)N * N;
     const double* Cb = Cneg + (size_t)b * M * NN;
     const double* Kb = K + (size_t)b * NN;
+    const double* Ab = alpha + (size_t)b * M * N;
     double* Co = C + (size_t)b * NN;
-    if (threadIdx.x < M) swB[threadIdx.x] = small[(size_t)b * small_per + threadIdx.x];
-    __syncthreads();
-    double tr[NMGP_MAX_OUTPUTS], tk[NMGP_MAX_OUTPUTS];
+    double wB[M];
 #pragma unroll
-    for (int p = 0; p < NMGP_MAX_OUTPUTS; ++p) tr[p] = tk[p] = 0.0;
+    for (int p = 0; p < M; ++p) wB[p] = small[(size_t)b * small_per + p];
+    double tr[M], tk[M], X[NX];
+#pragma unroll
+    for (int p = 0; p < M; ++p) tr[p] = tk[p] = 0.0;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) X[e] = 0.0;
     for (int j = g; j < N; j += G) {
+        double aj[M];
+#pragma unroll
+        for (int p = 0; p < M; ++p) aj[p] = Ab[(size_t)p * N + j];
         for (int i = j + threadIdx.x; i < N; i += 256) {
             const size_t o = (size_t)j * N + i;
             const double k = Kb[o];
+            double ai[M];
+#pragma unroll
+            for (int p = 0; p < M; ++p) ai[p] = Ab[(size_t)p * N + i];
             double cs = 0.0;
 #pragma unroll
-            for (int p = 0; p < NMGP_MAX_OUTPUTS; ++p) {
-                if (p < M) {
-                    const double c = -Cb[(size_t)p * NN + o];
-                    cs += swB[p] * c;
-                    if (i == j) {
-                        tr[p] += c;
-                        tk[p] += c * k;
-                    } else {
-                        tk[p] += 2.0 * c * k;
-                    }
+            for (int p = 0; p < M; ++p) {
+                const double c = -Cb[(size_t)p * NN + o];
+                cs += wB[p] * c;
+                if (i == j) {
+                    tr[p] += c;
+                    tk[p] += c * k;
+                } else {
+                    tk[p] += 2.0 * c * k;
                 }
             }
             Co[o] = cs;
+            // alpha_p^T K alpha_q: the element (i, j) and its mirror (j, i)
+            int e = 0;
+#pragma unroll
+            for (int p = 0; p < M; ++p) {
+#pragma unroll
+                for (int q = p; q < M; ++q) {
+                    const double t = (i == j) ? ai[p] * ai[q] : ai[p] * aj[q] + aj[p] * ai[q];
+                    X[e] = fma(k, t, X[e]);
+                    ++e;
+                }
+            }
         }
     }
+#pragma unroll
     for (int p = 0; p < M; ++p) {
         double aa = 0.0;
         if (g == 0) {
-            const double* ap = alpha + ((size_t)b * M + p) * N;
+            const double* ap = Ab + (size_t)p * N;
             for (int i = threadIdx.x; i < N; i += 256) aa += ap[i] * ap[i];
         }
-        double trp = 0.0, tkp = 0.0;
-#pragma unroll
-        for (int q = 0; q < NMGP_MAX_OUTPUTS; ++q)
-            if (q == p) {
-                trp = tr[q];
-                tkp = tk[q];
-            }
-        trp = block_sum_s(trp, sh);
-        tkp = block_sum_s(tkp, sh);
+        const double trp = block_sum_s(tr[p], sh), tkp = block_sum_s(tk[p], sh);
         aa = block_sum_s(aa, sh);
         if (threadIdx.x == 0) {
             double* o = out + (((size_t)b * M + p) * G + g) * 3;
@@ -334,11 +353,32 @@ __global__ __launch_bounds__(256) void k_sep_reduce_b(const double* __restrict__
             o[2] = aa;
         }
     }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+        const double v = block_sum_s(X[e], sh);
+        if (threadIdx.x == 0) xi[((size_t)b * G + g) * NX + e] = v;
+    }
 }
 
+template <int M>
+static void launch_sep_reduce_b(hipStream_t s, const double* Cneg, const double* K, const double* alpha, const double* small, int small_per,
+                                int N, int G, double* C, double* out, double* xi, int B) {
+    NMGP_LAUNCH((k_sep_reduce_b<M>), dim3(G, B), dim3(256), 0, s, Cneg, K, alpha, small, small_per, N, G, C, out, xi);
+}
+
+// xi: B * G * M (M + 1) / 2 doubles
 void sep_reduce_b(hipStream_t s, const double* Cneg, const double* K, const double* alpha, const double* small, int small_per, int N,
-                  int M, int G, double* C, double* out, int B) {
-    NMGP_LAUNCH(k_sep_reduce_b, dim3(G, B), dim3(256), 0, s, Cneg, K, alpha, small, small_per, N, M, G, C, out);
+                  int M, int G, double* C, double* out, double* xi, int B) {
+    switch (M) {
+        case 1: launch_sep_reduce_b<1>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 2: launch_sep_reduce_b<2>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 3: launch_sep_reduce_b<3>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 4: launch_sep_reduce_b<4>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 5: launch_sep_reduce_b<5>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 6: launch_sep_reduce_b<6>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        case 7: launch_sep_reduce_b<7>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+        default: launch_sep_reduce_b<8>(s, Cneg, K, alpha, small, small_per, N, G, C, out, xi, B); break;
+    }
 }
 
 // k_sep_adjoint (nmgp_kernels_eig.hip) with the chain as blockIdx.z:
